@@ -1,0 +1,173 @@
+/*
+ * sdice.h -- C ABI of libsplicedice_hip.so: the MI355X (gfx950) hot path of splicedice.
+ *
+ * The reference (BrooksLabUCSC/splicedice) is pure Python and has NO FFI/plugin
+ * interface; its only extension seam is add_cmd(name, add_parser, run_with)
+ * (splicedice/__main__.py:17-33).  This header is therefore the boundary a maintainer
+ * would bind with ctypes from inside the four hot `run_with` functions; each entry
+ * point cites the reference loop it replaces (file:line relative to the reference
+ * checkout).  See INTEGRATION.md for the ctypes stub.
+ *
+ * Conventions
+ *  - plain C, every function returns int status (0 = ok, <0 = error);
+ *    sdice_last_error() returns a thread-local message; no exceptions cross the ABI.
+ *  - host entry points (no suffix): caller owns all host buffers (C-contiguous,
+ *    pointer + explicit sizes); the call copies in, runs the HIP kernels, copies out and
+ *    is synchronous on return.
+ *  - device entry points (`_dev`): all pointers are device pointers obtained from
+ *    sdice_dmalloc; work is enqueued on the context's HIP stream and NOT synchronised
+ *    (call sdice_sync).  These keep tables resident in HBM between stages.
+ *  - a context is bound to one GPU and used from one thread at a time.
+ *  - there is no CPU backend: without a usable HIP device sdice_ctx_create fails.
+ */
+#ifndef SDICE_H
+#define SDICE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdice_ctx sdice_ctx;
+
+#define SDICE_OK          0
+#define SDICE_ERR_ARG    -1
+#define SDICE_ERR_HIP    -2
+#define SDICE_ERR_NOMEM  -3
+#define SDICE_ERR_STATE  -4
+#define SDICE_ERR_COMM   -5
+
+#define SDICE_ABI_VERSION 1
+
+/* ---- lifecycle / errors ---------------------------------------------------------- */
+int         sdice_version(void);
+const char* sdice_last_error(void);
+int         sdice_ctx_create(int device_ordinal, sdice_ctx** out);
+int         sdice_ctx_destroy(sdice_ctx* ctx);
+int         sdice_sync(sdice_ctx* ctx);
+/* name: caller buffer of name_cap bytes; any out pointer may be NULL */
+int         sdice_device_info(sdice_ctx* ctx, char* name, int name_cap, int* compute_units,
+                              int64_t* hbm_bytes);
+
+/* ---- device memory (for the _dev entry points) ------------------------------------ */
+int sdice_dmalloc(sdice_ctx* ctx, int64_t bytes, void** dptr);
+int sdice_dfree(sdice_ctx* ctx, void* dptr);
+int sdice_h2d(sdice_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int sdice_d2h(sdice_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+int sdice_dmemset(sdice_ctx* ctx, void* dptr, int value, int64_t bytes);
+
+/* ---- clustering: replaces SPLICEDICE.getClusters (SPLICEDICE.py:230-255), its twin
+ *      counts_to_ps.determine_clusters (counts_to_ps.py:16-41) and the junctionIndex
+ *      sort (SPLICEDICE.py:96).
+ *  in : n junctions as parallel arrays, any order, all distinct.
+ *       chrom_rank = dense rank of the chromosome name under Python string sort,
+ *       0 <= left <= right < 2^31, strand 0 = '+', 1 = '-'.
+ *  out: row_of[n]   output row of input junction i = its rank in
+ *                   (chrom, left, right, strand) order (SPLICEDICE.py:96);
+ *       row_ptr[n+1], col[nnz]: per output row, the rows of all junctions on the same
+ *                   chromosome+strand whose closed interval overlaps it
+ *                   (prior.right >= cur.left, SPLICEDICE.py:250), in the reference's
+ *                   list order: earlier-in-sweep overlaps most recent first, then
+ *                   later ones in sweep order.
+ *  The column list lives in the context until the next sdice_cluster* call and is
+ *  fetched with sdice_cluster_col (host) / sdice_cluster_col_dev (device pointer).
+ */
+int sdice_cluster(sdice_ctx* ctx, int64_t n, const int32_t* chrom_rank, const int32_t* left,
+                  const int32_t* right, const int8_t* strand,
+                  int32_t* row_of, int64_t* row_ptr, int64_t* nnz);
+int sdice_cluster_col(sdice_ctx* ctx, int32_t* col, int64_t capacity);
+int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom_rank,
+                      const int32_t* d_left, const int32_t* d_right, const int8_t* d_strand,
+                      int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz /* host out, or NULL to stay asynchronous */);
+int sdice_cluster_col_dev(sdice_ctx* ctx, const int32_t** d_col, int64_t* nnz);
+
+/* ---- PS: replaces SPLICEDICE.calculatePsi (SPLICEDICE.py:297-310), counts_to_ps
+ *      writePsValues' arithmetic (counts_to_ps.py:63-68) and pairwise's exclusion
+ *      gather (pairwise_fisher.py:158-160).
+ *  counts[n,s] int32 row-major, rows in output-row order; CSR as above (any valid CSR
+ *  over rows is accepted, e.g. one parsed from an _allClusters.tsv).
+ *  excl[n,s] int64 (optional, may be NULL): sum of the count rows of the neighbours.
+ *  ps[n,s] float32 (optional, may be NULL) = float32(double(incl) / double(incl+excl));
+ *  0/0 -> NaN.
+ */
+int sdice_ps(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* counts,
+             const int64_t* row_ptr, const int32_t* col, int64_t* excl, float* ps);
+int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* d_counts,
+                 const int64_t* d_row_ptr, const int32_t* d_col, int64_t* d_excl, float* d_ps);
+
+/* --lowCoverageNan (SPLICEDICE.py:307-309): ps[low_idx[i]] = NaN, flat indices r*s+c */
+int sdice_mark_low(sdice_ctx* ctx, int64_t n_elems, float* ps, const int64_t* low_idx,
+                   int64_t n_low);
+int sdice_mark_low_dev(sdice_ctx* ctx, int64_t n_elems, float* d_ps, const int64_t* d_low_idx,
+                       int64_t n_low);
+
+/* the `_allPS.tsv` text round trip between quant and compare_sample_sets:
+ * f'{x:.3f}' (SPLICEDICE.py:353) re-read as float32 (compareSampleSets.py:202) */
+int sdice_quantize3(sdice_ctx* ctx, int64_t n_elems, float* ps_inout);
+int sdice_quantize3_dev(sdice_ctx* ctx, int64_t n_elems, float* d_ps_inout);
+
+/* ---- compare_sample_sets: replaces the per-row loop compareSampleSets.py:216-232
+ *      (NaN drop, <3 skip, scipy.stats.ranksums, np.median x2, np.mean x2).
+ *  ps[n,s] float32; g1[n1], g2[n2] column indices (table order).
+ *  Outputs are un-compacted, one slot per row: tested[n] (1 = row was tested),
+ *  p[n] float64, med1/med2/mean1/mean2/delta[n] float32 (0 where not tested);
+ *  z[n] float64 optional (NULL to skip).  The host compacts in row order.
+ */
+int sdice_ranksum(sdice_ctx* ctx, int64_t n, int32_t s, const float* ps,
+                  const int32_t* g1, int32_t n1, const int32_t* g2, int32_t n2,
+                  uint8_t* tested, double* p, double* z, float* med1, float* med2,
+                  float* mean1, float* mean2, float* delta);
+int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const float* d_ps,
+                      const int32_t* d_g1, int32_t n1, const int32_t* d_g2, int32_t n2,
+                      uint8_t* d_tested, double* d_p, double* d_z, float* d_med1, float* d_med2,
+                      float* d_mean1, float* d_mean2, float* d_delta);
+
+/* ---- pairwise: replaces the per-pair loop pairwise_fisher.py:164-179
+ *      (scipy.stats.fisher_exact two-sided on [[incl_a, incl_b],[excl_a, excl_b]]).
+ *  incl[n,s] int32, excl[n,s] int64 (from sdice_ps); p[n, s(s-1)/2] float64 row-major,
+ *  pair order (0,1),(0,2)...(s-2,s-1) (pairwise_fisher.py:142-147).
+ */
+int sdice_fisher_pairs(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* incl,
+                       const int64_t* excl, double* p);
+int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* d_incl,
+                           const int64_t* d_excl, double* d_p);
+/* m independent 2x2 tables abcd[m,4] int64 -> p[m] (same kernel math; KAT entry point) */
+int sdice_fisher_tables(sdice_ctx* ctx, int64_t m, const int64_t* abcd, double* p);
+
+/* ---- Benjamini-Hochberg: replaces statsmodels multipletests(p, method="fdr_bh")[1]
+ *      (compareSampleSets.py:235; pairwise_fisher.py:185,190). */
+int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q);
+int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double* d_q);
+/* BH down each of `cols` columns of a row-major [n, cols] table, in place
+ * (pairwise_fisher.py:187-191) */
+int sdice_bh_columns(sdice_ctx* ctx, int64_t n, int64_t cols, double* p_inout);
+
+/* ---- multi-GPU (new; the reference is single-process): one context per rank,
+ *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque
+ *      bytes created on rank 0 and distributed by the caller (any channel). */
+#define SDICE_COMM_ID_BYTES 128
+int sdice_comm_unique_id(sdice_ctx* ctx, void* id_out);
+int sdice_comm_init(sdice_ctx* ctx, const void* id, int rank, int world);
+int sdice_comm_destroy(sdice_ctx* ctx);
+/* all-gather equal-sized row shards: recv holds world * bytes_per_rank */
+int sdice_allgather_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+
+/* ---- per-kernel timing with HIP events on the context's stream ---------------------- */
+int sdice_prof_enable(sdice_ctx* ctx, int on);
+int sdice_prof_reset(sdice_ctx* ctx);
+/* total device time and launch count of kernel `name` since the last reset (syncs) */
+int sdice_prof_query(sdice_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
+/* newline-separated "name launches total_ms" table into buf */
+int sdice_prof_report(sdice_ctx* ctx, char* buf, int cap);
+/* stream-level stopwatch (hipEvents on the context stream) */
+int sdice_timer_start(sdice_ctx* ctx);
+int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms);
+
+/* tuning knob (integer parameters by name, e.g. "ps.tile_rows"); unknown name -> ERR_ARG */
+int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDICE_H */

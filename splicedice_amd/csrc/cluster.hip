@@ -1,0 +1,318 @@
+// K1 + K2: interval sort and overlap "clusters" (per-junction adjacency lists).
+//
+// Replaces SPLICEDICE.getClusters (SPLICEDICE.py:230-255; twin counts_to_ps.py:16-41) and
+// the junctionIndex sort (SPLICEDICE.py:96).  The reference sorts junctions by
+// (chrom, strand, left, right) and sweeps, keeping a most-recent-first list of still-open
+// prior junctions; two junctions on one chromosome+strand are neighbours iff their closed
+// intervals overlap (prior.right >= cur.left, :250).  Output rows use a DIFFERENT order,
+// (chrom, left, right, strand) (:96).  Per junction the neighbour list order is: earlier
+// junctions of the sweep, most recent first, then later ones in sweep order.
+//
+// Device formulation (no sweep): in sweep order p, with composite keys
+//   ckL[p] = seg<<32 | left,  ckR[p] = seg<<32 | right,   seg = chrom<<1 | strand
+//   * later neighbours of p are the contiguous range (p, ub_p),
+//       ub_p = upper_bound(ckL, seg_p<<32 | right_p)           (galloping binary search)
+//   * earlier neighbours are the q < p with ckR[q] >= seg_p<<32 | left_p; the backward walk
+//     stops at the first q whose running prefix maximum of ckR drops below the target and
+//     skips 64-aligned blocks whose block maximum is below it.
+//   degree -> exclusive scan (row order) -> fill.
+#include "common.h"
+
+int sd_inclusive_max_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, uint64_t* d_out);
+
+namespace {
+
+// red[0]=OR(keyQ) red[1]=AND(keyQ) red[2]=OR(chrom) red[3]=AND(chrom) red[4]=error flag
+__global__ void __launch_bounds__(256) build_keys_kernel(const int32_t* __restrict__ chrom,
+                                                         const int32_t* __restrict__ left,
+                                                         const int32_t* __restrict__ right,
+                                                         const int8_t* __restrict__ strand, int64_t n,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                         unsigned long long* __restrict__ red) {
+    __shared__ unsigned long long sh[5][4];
+    unsigned long long o1 = 0, a1 = ~0ull, o2 = 0, a2 = ~0ull, err = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t l = left[i], r = right[i], c = chrom[i];
+        const int st = strand[i];
+        if (l < 0 || r < l || c < 0 || (st != 0 && st != 1)) err = 1;
+        const uint64_t k = ((uint64_t)(uint32_t)l << 32) | ((uint64_t)(uint32_t)r << 1) | (uint64_t)(st & 1);
+        keys[i] = k;
+        idx[i] = (uint32_t)i;
+        o1 |= k; a1 &= k;
+        o2 |= (uint64_t)(uint32_t)c; a2 &= (uint64_t)(uint32_t)c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        o1 |= __shfl_xor(o1, o); a1 &= __shfl_xor(a1, o);
+        o2 |= __shfl_xor(o2, o); a2 &= __shfl_xor(a2, o);
+        err |= __shfl_xor(err, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = o1; sh[1][w] = a1; sh[2][w] = o2; sh[3][w] = a2; sh[4][w] = err; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            sh[0][0] |= sh[0][k]; sh[1][0] &= sh[1][k]; sh[2][0] |= sh[2][k]; sh[3][0] &= sh[3][k]; sh[4][0] |= sh[4][k];
+        }
+        atomicOr(&red[0], sh[0][0]);
+        atomicAnd(&red[1], sh[1][0]);
+        atomicOr(&red[2], sh[2][0]);
+        atomicAnd(&red[3], sh[3][0]);
+        if (sh[4][0]) atomicOr(&red[4], 1ull);
+    }
+}
+
+__global__ void __launch_bounds__(256) gather_chrom_kernel(const int32_t* __restrict__ chrom,
+                                                           const uint32_t* __restrict__ idx, int64_t n,
+                                                           uint64_t* __restrict__ key2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key2[i] = (uint64_t)(uint32_t)chrom[idx[i]];
+}
+
+// rows are in (chrom,left,right,strand) order: perm[r] = input index of row r
+__global__ void __launch_bounds__(256) rows_kernel(const uint32_t* __restrict__ perm,
+                                                   const int32_t* __restrict__ chrom,
+                                                   const int32_t* __restrict__ left,
+                                                   const int32_t* __restrict__ right,
+                                                   const int8_t* __restrict__ strand, int64_t n,
+                                                   int32_t* __restrict__ row_of, uint64_t* __restrict__ key3,
+                                                   uint32_t* __restrict__ rid, int32_t* __restrict__ rowL,
+                                                   int32_t* __restrict__ rowR) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t i = perm[r];
+    row_of[i] = (int32_t)r;
+    key3[r] = ((uint64_t)(uint32_t)chrom[i] << 1) | (uint64_t)(strand[i] & 1);
+    rid[r] = (uint32_t)r;
+    rowL[r] = left[i];
+    rowR[r] = right[i];
+}
+
+// sweep order: srow[p] = row at sweep position p, seg[p] = its (chrom<<1|strand)
+__global__ void __launch_bounds__(256) sweep_keys_kernel(const uint64_t* __restrict__ seg,
+                                                         const uint32_t* __restrict__ srow,
+                                                         const int32_t* __restrict__ rowL,
+                                                         const int32_t* __restrict__ rowR, int64_t n,
+                                                         uint64_t* __restrict__ ckL, uint64_t* __restrict__ ckR) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t r = srow[p];
+    const uint64_t s = seg[p] << 32;
+    ckL[p] = s | (uint32_t)rowL[r];
+    ckR[p] = s | (uint32_t)rowR[r];
+}
+
+__global__ void __launch_bounds__(64) blockmax_kernel(const uint64_t* __restrict__ ckR, int64_t n,
+                                                      uint64_t* __restrict__ bmax) {
+    const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    uint64_t v = p < n ? ckR[p] : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t y = __shfl_xor(v, o);
+        v = y > v ? y : v;
+    }
+    if (threadIdx.x == 0) bmax[blockIdx.x] = v;
+}
+
+__device__ __forceinline__ int64_t upper_bound_from(const uint64_t* __restrict__ ck, int64_t p, int64_t n,
+                                                    uint64_t target) {
+    // first q > p with ck[q] > target (ck sorted non-decreasing); gallop then bisect
+    int64_t lo = p + 1, step = 1;
+    int64_t hi = lo;
+    while (hi < n && ck[hi] <= target) { lo = hi + 1; hi += step; step <<= 1; }
+    if (hi > n) hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (ck[mid] <= target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) neighbours_kernel(const uint64_t* __restrict__ ckL,
+                                                         const uint64_t* __restrict__ ckR,
+                                                         const uint64_t* __restrict__ pmax,
+                                                         const uint64_t* __restrict__ bmax,
+                                                         const uint32_t* __restrict__ srow, int64_t n,
+                                                         int64_t* __restrict__ deg /* by row (count pass) */,
+                                                         const int64_t* __restrict__ row_ptr,
+                                                         int32_t* __restrict__ col) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t seg_hi = ckL[p] & 0xffffffff00000000ull;
+    const uint64_t tgt_r = seg_hi | (ckR[p] & 0xffffffffull);  // later: ckL[q] <= seg|right_p
+    const uint64_t tgt_l = ckL[p];                             // earlier: ckR[q] >= seg|left_p
+    const uint32_t row = srow[p];
+    const int64_t ub = upper_bound_from(ckL, p, n, tgt_r);
+    int64_t cnt = 0;
+    int32_t* out = FILL ? col + row_ptr[row] : nullptr;
+    // earlier neighbours, most recent first
+    int64_t q = p - 1;
+    while (q >= 0 && pmax[q] >= tgt_l) {
+        if ((q & 63) == 63 && bmax[q >> 6] < tgt_l) { q -= 64; continue; }
+        if (ckR[q] >= tgt_l) {
+            if (FILL) out[cnt] = (int32_t)srow[q];
+            ++cnt;
+        }
+        --q;
+    }
+    if (FILL) {
+        for (int64_t t = p + 1; t < ub; ++t) out[cnt++] = (int32_t)srow[t];
+    } else {
+        deg[row] = cnt + (ub - p - 1);
+    }
+}
+
+inline unsigned grid_for(int64_t n, int threads) { return (unsigned)sd_ceil_div(n, threads); }
+
+}  // namespace
+
+extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left,
+                                 const int32_t* d_right, const int8_t* d_strand, int32_t* d_row_of,
+                                 int64_t* d_row_ptr, int64_t* nnz_out) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
+    SD_HIP(hipSetDevice(ctx->device));
+    ctx->nnz = 0;
+    if (nnz_out) *nnz_out = 0;
+    if (n == 0) {
+        if (d_row_ptr) SD_HIP(hipMemsetAsync(d_row_ptr, 0, 8, ctx->stream));
+        return SDICE_OK;
+    }
+    SD_ARG(d_chrom && d_left && d_right && d_strand && d_row_of && d_row_ptr, "NULL pointer");
+    SD_TRY(ctx->arena.reset(ctx->stream));
+    Arena& A = ctx->arena;
+    const size_t N = (size_t)n;
+    uint64_t* kA = (uint64_t*)A.alloc(N * 8);
+    uint64_t* kB = (uint64_t*)A.alloc(N * 8);
+    uint64_t* kC = (uint64_t*)A.alloc(N * 8);
+    uint32_t* vA = (uint32_t*)A.alloc(N * 4);
+    uint32_t* vB = (uint32_t*)A.alloc(N * 4);
+    uint32_t* vC = (uint32_t*)A.alloc(N * 4);
+    int32_t* rowL = (int32_t*)A.alloc(N * 4);
+    int32_t* rowR = (int32_t*)A.alloc(N * 4);
+    int64_t* deg = (int64_t*)A.alloc((N + 1) * 8);
+    unsigned long long* red = (unsigned long long*)A.alloc(64);
+    const int64_t nb64 = sd_ceil_div(n, 64);
+    uint64_t* bmax = (uint64_t*)A.alloc((size_t)nb64 * 8);
+    if (!kA || !kB || !kC || !vA || !vB || !vC || !rowL || !rowR || !deg || !red || !bmax) return SDICE_ERR_NOMEM;
+
+    // ---- keys + varying-bit masks
+    ctx->h_pinned[0] = 0; ctx->h_pinned[1] = -1; ctx->h_pinned[2] = 0; ctx->h_pinned[3] = -1; ctx->h_pinned[4] = 0;
+    SD_HIP(hipMemcpyAsync(red, ctx->h_pinned, 40, hipMemcpyHostToDevice, ctx->stream));
+    {
+        int64_t blocks = sd_ceil_div(n, 256);
+        if (blocks > 1024) blocks = 1024;
+        SD_LAUNCH(ctx, "build_keys_kernel", build_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, d_chrom, d_left,
+                  d_right, d_strand, n, kA, vA, red);
+    }
+    SD_HIP(hipMemcpyAsync(ctx->h_pinned + 8, red, 40, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t maskQ = (uint64_t)ctx->h_pinned[8] ^ (uint64_t)ctx->h_pinned[9];
+    const uint64_t maskC = ((uint64_t)ctx->h_pinned[10] ^ (uint64_t)ctx->h_pinned[11]) & 0xffffffffull;
+    if (ctx->h_pinned[12]) {
+        sdice_set_error("sdice_cluster: invalid junction (need 0 <= left <= right, chrom_rank >= 0, strand in {0,1})");
+        return SDICE_ERR_ARG;
+    }
+
+    // ---- row order (chrom, left, right, strand): sort by key, then stably by chrom
+    SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vA, kB, vB, kC, vC, maskQ));   // -> kB, vB
+    const uint32_t* perm = vB;
+    if (maskC) {
+        SD_LAUNCH(ctx, "gather_chrom_kernel", gather_chrom_kernel, dim3(grid_for(n, 256)), dim3(256), 0, d_chrom, vB, n,
+                  kA);
+        SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vB, kC, vA, kB, vC, maskC));   // -> kC, vA
+        perm = vA;
+    }
+    // ---- per-row data, then sweep order (chrom, strand, left, right) by one more stable sort
+    uint64_t* key3 = kA;
+    uint32_t* rid = (perm == vA) ? vB : vA;
+    SD_LAUNCH(ctx, "rows_kernel", rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, perm, d_chrom, d_left, d_right,
+              d_strand, n, d_row_of, key3, rid, rowL, rowR);
+    const uint64_t mask3 = (maskC << 1) | (maskQ & 1ull);
+    uint32_t* srow = (rid == vA) ? vB : vA;   // perm no longer needed after rows_kernel
+    SD_TRY(sd_radix_sort_pairs(ctx, n, key3, rid, kB, srow, kC, vC, mask3));   // -> kB (seg), srow
+    uint64_t* seg = kB;
+    uint64_t* ckL = kA;   // key3 dead
+    uint64_t* ckR = kC;
+    SD_LAUNCH(ctx, "sweep_keys_kernel", sweep_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, seg, srow, rowL, rowR, n,
+              ckL, ckR);
+    uint64_t* pmax = kB;  // seg dead after sweep_keys
+    SD_TRY(sd_inclusive_max_scan_u64(ctx, n, ckR, pmax));
+    SD_LAUNCH(ctx, "blockmax_kernel", blockmax_kernel, dim3((unsigned)nb64), dim3(64), 0, ckR, n, bmax);
+
+    // ---- degrees -> row_ptr
+    SD_HIP(hipMemsetAsync(deg + n, 0, 8, ctx->stream));
+    SD_LAUNCH(ctx, "neighbours_count_kernel", (neighbours_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
+              pmax, bmax, srow, n, deg, (const int64_t*)nullptr, (int32_t*)nullptr);
+    SD_TRY(sd_exclusive_scan_i64(ctx, n + 1, deg, d_row_ptr, nullptr));
+    SD_HIP(hipMemcpyAsync(ctx->h_pinned + 16, d_row_ptr + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t nnz = ctx->h_pinned[16];
+    if (nnz > ctx->col_cap) {
+        if (ctx->d_col) (void)hipFree(ctx->d_col);
+        ctx->d_col = nullptr;
+        ctx->col_cap = 0;
+        const int64_t cap = nnz + nnz / 8 + 1024;
+        hipError_t e = hipMalloc((void**)&ctx->d_col, (size_t)cap * 4);
+        if (e != hipSuccess) {
+            sdice_set_error("sdice_cluster: hipMalloc of %lld neighbour indices failed: %s", (long long)cap,
+                            hipGetErrorString(e));
+            return SDICE_ERR_NOMEM;
+        }
+        ctx->col_cap = cap;
+    }
+    if (nnz > 0)
+        SD_LAUNCH(ctx, "neighbours_fill_kernel", (neighbours_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
+                  pmax, bmax, srow, n, (int64_t*)nullptr, (const int64_t*)d_row_ptr, ctx->d_col);
+    ctx->nnz = nnz;
+    if (nnz_out) *nnz_out = nnz;
+    return SDICE_OK;
+}
+
+extern "C" int sdice_cluster_col_dev(sdice_ctx* ctx, const int32_t** d_col, int64_t* nnz) {
+    SD_ARG(ctx && d_col, "bad arguments");
+    *d_col = ctx->d_col;
+    if (nnz) *nnz = ctx->nnz;
+    return SDICE_OK;
+}
+
+extern "C" int sdice_cluster(sdice_ctx* ctx, int64_t n, const int32_t* chrom_rank, const int32_t* left,
+                             const int32_t* right, const int8_t* strand, int32_t* row_of, int64_t* row_ptr,
+                             int64_t* nnz) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
+    SD_ARG(row_ptr, "row_ptr is NULL");
+    if (n == 0) { row_ptr[0] = 0; if (nnz) *nnz = 0; ctx->nnz = 0; return SDICE_OK; }
+    SD_ARG(chrom_rank && left && right && strand && row_of, "NULL pointer");
+    int32_t *dc = nullptr, *dl = nullptr, *dr = nullptr, *drow = nullptr;
+    int8_t* ds = nullptr;
+    int64_t* drp = nullptr;
+    int rc = sdice_dmalloc(ctx, n * 4, (void**)&dc);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * 4, (void**)&dl);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * 4, (void**)&dr);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n, (void**)&ds);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * 4, (void**)&drow);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, (n + 1) * 8, (void**)&drp);
+    if (rc == SDICE_OK) rc = sdice_h2d(ctx, dc, chrom_rank, n * 4);
+    if (rc == SDICE_OK) rc = sdice_h2d(ctx, dl, left, n * 4);
+    if (rc == SDICE_OK) rc = sdice_h2d(ctx, dr, right, n * 4);
+    if (rc == SDICE_OK) rc = sdice_h2d(ctx, ds, strand, n);
+    int64_t z = 0;
+    if (rc == SDICE_OK) rc = sdice_cluster_dev(ctx, n, dc, dl, dr, ds, drow, drp, &z);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, row_of, drow, n * 4);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, row_ptr, drp, (n + 1) * 8);
+    if (rc == SDICE_OK && nnz) *nnz = z;
+    sdice_dfree(ctx, dc); sdice_dfree(ctx, dl); sdice_dfree(ctx, dr); sdice_dfree(ctx, ds);
+    sdice_dfree(ctx, drow); sdice_dfree(ctx, drp);
+    return rc;
+}
+
+extern "C" int sdice_cluster_col(sdice_ctx* ctx, int32_t* col, int64_t capacity) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(capacity >= ctx->nnz, "capacity smaller than nnz");
+    if (ctx->nnz == 0) return SDICE_OK;
+    SD_ARG(col, "col is NULL");
+    return sdice_d2h(ctx, col, ctx->d_col, ctx->nnz * 4);
+}

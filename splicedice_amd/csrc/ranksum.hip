@@ -1,0 +1,514 @@
+// K5: two-group Wilcoxon rank-sum per junction row + per-group median / mean.
+//
+// Replaces the row loop of compare_sample_sets (compareSampleSets.py:216-232):
+//   d1 = row[g1], d2 = row[g2]; drop NaNs; skip the row if either group has < 3 values;
+//   scipy.stats.ranksums(d1, d2)  (average ranks, no tie / continuity correction,
+//   p = 2*ndtr(-|z|)); np.median x2, np.mean x2 on float32; delta = med1 - med2.
+//
+// Arithmetic used here (exact restatement, not an approximation):
+//   sum of ranks of group 1 = n1(n1+1)/2 + U,  U = #{(i,j): b_j < a_i} + 0.5 #{b_j == a_i}
+//   => s - expected = U - n1*n2/2  (half-integers, exact), z = that / sqrt(n1 n2 (n1+n2+1)/12).
+//   2U = sum_i (lower_bound(B, a_i) + upper_bound(B, a_i)) over the sorted second group.
+//   np.mean(float32 vector) = numpy's pairwise summation in float32 (8 interleaved
+//   accumulators per <=128-element block, halving recursion above) divided by n in float32;
+//   it is reproduced operation for operation so the means are bit-identical.
+//
+// Two kernels:
+//   ranksum_lane_kernel  (n1, n2 <= 64): one LANE per row.  A wave stages 64 rows (only the
+//       selected columns) into LDS with a coalesced copy, each lane then compacts its row,
+//       sums it, sorts each group with a fully unrolled bitonic network held in VGPRs
+//       (v_min/v_max pairs, no cross-lane traffic), writes the sorted groups back to LDS and
+//       merges them for U.  All 64 lanes stay busy on serial per-row work.
+//   ranksum_block_kernel (any n1, n2 that fit LDS): one workgroup per row, bitonic sort in
+//       LDS, binary searches for U.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct RsOut {
+    uint8_t* tested;
+    double* p;
+    double* z;
+    float* med1;
+    float* med2;
+    float* mean1;
+    float* mean2;
+    float* delta;
+};
+
+__device__ __forceinline__ void rs_finish(int nv1, int nv2, long long u2, double& z, double& p) {
+    // scipy ranksums: z = (s - n1(n1+n2+1)/2) / sqrt(n1 n2 (n1+n2+1)/12), s - expected = U - n1 n2/2
+    const double num = 0.5 * (double)(u2 - (long long)nv1 * (long long)nv2);
+    const double den = sqrt((double)((long long)nv1 * nv2 * (nv1 + nv2 + 1)) / 12.0);
+    z = num / den;
+    const double x = -fabs(z) * 0.70710678118654752440;  // cephes ndtr(-|z|)
+    const double y = (fabs(x) < 0.70710678118654752440) ? 0.5 + 0.5 * erf(x) : 0.5 * erfc(-x);
+    p = 2.0 * y;
+}
+
+// ------------------------------------------------------------------ lane-per-row variant
+template <int P>
+__device__ __forceinline__ void bitonic_regs(float (&a)[P]) {
+#pragma unroll
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool asc = (i & k) == 0;
+                    const float lo = __builtin_fminf(a[i], a[l]);
+                    const float hi = __builtin_fmaxf(a[i], a[l]);
+                    a[i] = asc ? lo : hi;
+                    a[l] = asc ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+// One group of one row, handled by one lane.  row: this lane's slice of the LDS tile (group
+// values at [0, cnt)).  Compacts in place (NaNs dropped, order kept), returns the number of
+// valid values, the float32 pairwise mean, and leaves the group SORTED in row[0..nv).
+template <int P>
+__device__ __forceinline__ int lane_group(float* row, int cnt, float& mean) {
+    int nv = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const float x = row[k];
+        if (x == x) { row[nv] = x; ++nv; }
+    }
+    float a[P];
+    const float inf = __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < P; ++k) a[k] = (k < nv) ? row[k] : inf;
+    // numpy pairwise_sum (n <= 128 -> single block), npy loops_utils.h.src
+    float res;
+    if (nv < 8) {
+        res = 0.f;
+#pragma unroll
+        for (int k = 0; k < (P < 8 ? P : 7); ++k)
+            if (k < nv) res += a[k];
+    } else {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        const int main_n = nv - (nv & 7);
+#pragma unroll
+        for (int k = 8; k < P; ++k)
+            if (k < main_n) r[k & 7] += a[k];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int k = 8; k < P; ++k)
+            if (k >= main_n && k < nv) res += a[k];
+    }
+    mean = nv > 0 ? res / (float)nv : 0.f;
+    bitonic_regs<P>(a);
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        if (k < cnt) row[k] = a[k];
+    return nv;
+}
+
+__device__ __forceinline__ float median_sorted(const float* a, int nv) {
+    // np.median: odd -> middle; even -> np.mean of the two middle values in float32
+    const int h = nv >> 1;
+    if (nv & 1) return a[h];
+    return (a[h - 1] + a[h]) / 2.0f;
+}
+
+template <int P1, int P2>
+__global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restrict__ ps, int64_t n, int s,
+                                                           const int32_t* __restrict__ gsel, int n1, int n2,
+                                                           int stride, RsOut o) {
+    extern __shared__ float smemf[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    float* tile = smemf + (size_t)wave * 64 * stride;
+    const int nsel = n1 + n2;
+    const int64_t n_groups = (n + 63) >> 6;
+    for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
+         g += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t row0 = g << 6;
+        // ---- stage 64 rows x nsel selected columns (coalesced along the row)
+        {
+            int r = lane / nsel, k = lane - r * nsel;
+            const int dr = 64 / nsel, dk = 64 - dr * nsel;
+            const int total = 64 * nsel;
+            for (int e = lane; e < total; e += 64) {
+                const int64_t row = row0 + r;
+                float x = __builtin_nanf("");
+                if (row < n) x = ps[row * s + gsel[k]];
+                tile[r * stride + k] = x;
+                k += dk; r += dr;
+                if (k >= nsel) { k -= nsel; r += 1; }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- per-lane serial work on row (row0 + lane)
+        float* row = tile + lane * stride;
+        float mean1, mean2;
+        const int nv1 = lane_group<P1>(row, n1, mean1);
+        const int nv2 = lane_group<P2>(row + n1, n2, mean2);
+        const int64_t rr = row0 + lane;
+        if (rr < n) {
+            const bool tested = nv1 >= 3 && nv2 >= 3;
+            float med1 = 0.f, med2 = 0.f, dl = 0.f;
+            double z = 0.0, p = 0.0;
+            if (tested) {
+                const float* A = row;
+                const float* B = row + n1;
+                med1 = median_sorted(A, nv1);
+                med2 = median_sorted(B, nv2);
+                dl = med1 - med2;
+                // 2U by a two-pointer merge of the sorted groups
+                long long u2 = 0;
+                int jl = 0, je = 0;
+                for (int i = 0; i < nv1; ++i) {
+                    const float ai = A[i];
+                    while (jl < nv2 && B[jl] < ai) ++jl;
+                    if (je < jl) je = jl;
+                    while (je < nv2 && B[je] <= ai) ++je;
+                    u2 += jl + je;
+                }
+                rs_finish(nv1, nv2, u2, z, p);
+            } else {
+                mean1 = 0.f; mean2 = 0.f;
+            }
+            o.tested[rr] = tested ? 1 : 0;
+            o.p[rr] = p;
+            if (o.z) o.z[rr] = z;
+            o.med1[rr] = med1; o.med2[rr] = med2;
+            o.mean1[rr] = mean1; o.mean2[rr] = mean2;
+            o.delta[rr] = dl;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ block-per-row variant
+constexpr int RB_THREADS = 256;
+
+// ordered compaction of the non-NaN values of ps[row, idx[0..cnt)] into dst; returns count
+__device__ int block_compact(const float* __restrict__ prow, const int32_t* __restrict__ idx, int cnt,
+                             float* dst, int* wcnt /* [RB_THREADS/64 + 1] shared */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int base = 0;
+    for (int c0 = 0; c0 < cnt; c0 += RB_THREADS) {
+        const int k = c0 + tid;
+        float x = __builtin_nanf("");
+        if (k < cnt) x = prow[idx[k]];
+        const bool valid = x == x;
+        const unsigned long long m = __ballot(valid);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int q = 0; q < RB_THREADS / 64; ++q) {
+            if (q < w) woff += wcnt[q];
+            tot += wcnt[q];
+        }
+        if (valid) dst[base + woff + pre] = x;
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
+// numpy pairwise_sum over a[0..n) in float32, any n, by the whole block; result to all threads
+__device__ float block_pairwise_sum(const float* a, int n, int* leaf_off /*[LEAF_MAX+1]*/, float* leaf_sum,
+                                    float* scratch8 /* [LEAF_MAX*8] */, int leaf_max) {
+    const int tid = threadIdx.x;
+    __shared__ int n_leaves_s;
+    __shared__ float result_s;
+    if (tid == 0) {
+        // leaves of the recursion `n2 = n/2; n2 -= n2 % 8; sum(a, n2) + sum(a+n2, n-n2)` in order
+        int st_off[32], st_len[32], sp = 0, nl = 0;
+        st_off[0] = 0; st_len[0] = n; sp = 1;
+        while (sp > 0) {
+            --sp;
+            const int off = st_off[sp], len = st_len[sp];
+            if (len <= 128 || nl >= leaf_max - 1) {
+                leaf_off[nl++] = off;
+            } else {
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                st_off[sp] = off + n2; st_len[sp] = len - n2; ++sp;   // right, popped second
+                st_off[sp] = off; st_len[sp] = n2; ++sp;             // left, popped first
+            }
+        }
+        leaf_off[nl] = n;
+        n_leaves_s = nl;
+    }
+    __syncthreads();
+    const int nl = n_leaves_s;
+    for (int t = tid; t < nl * 8; t += blockDim.x) {
+        const int L = t >> 3, j = t & 7;
+        const int off = leaf_off[L], len = leaf_off[L + 1] - off;
+        float r = 0.f;
+        if (len >= 8) {
+            r = a[off + j];
+            for (int i = 8; i < len - (len % 8); i += 8) r += a[off + i + j];
+        }
+        scratch8[t] = r;
+    }
+    __syncthreads();
+    for (int L = tid; L < nl; L += blockDim.x) {
+        const int off = leaf_off[L], len = leaf_off[L + 1] - off;
+        float res;
+        if (len < 8) {
+            res = 0.f;
+            for (int i = 0; i < len; ++i) res += a[off + i];
+        } else {
+            const float* r = scratch8 + L * 8;
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (int i = len - (len % 8); i < len; ++i) res += a[off + i];
+        }
+        leaf_sum[L] = res;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // re-walk the recursion, combining leaf sums in post-order
+        int st_len[32], st_state[32];
+        float st_val[32];
+        int sp = 0, next = 0;
+        float ret = 0.f;
+        st_len[0] = n; st_state[0] = 0; sp = 1;
+        while (sp > 0) {
+            const int len = st_len[sp - 1];
+            int& state = st_state[sp - 1];
+            if (state == 0) {
+                if (len <= 128 || sp >= 31) { ret = leaf_sum[next++]; --sp; continue; }
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                state = 1;
+                st_len[sp] = n2; st_state[sp] = 0; ++sp;
+            } else if (state == 1) {
+                st_val[sp - 1] = ret;
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                state = 2;
+                st_len[sp] = len - n2; st_state[sp] = 0; ++sp;
+            } else {
+                ret = st_val[sp - 1] + ret;
+                --sp;
+            }
+        }
+        result_s = ret;
+    }
+    __syncthreads();
+    const float out = result_s;
+    __syncthreads();
+    return out;
+}
+
+__global__ void __launch_bounds__(RB_THREADS) ranksum_block_kernel(const float* __restrict__ ps, int64_t n, int s,
+                                                                   const int32_t* __restrict__ g1, int n1,
+                                                                   const int32_t* __restrict__ g2, int n2, int P1,
+                                                                   int P2, int leaf_max, RsOut o) {
+    extern __shared__ float smemf[];
+    float* A = smemf;             // [P1]
+    float* B = A + P1;            // [P2]
+    float* leaf_sum = B + P2;     // [leaf_max]
+    float* scratch8 = leaf_sum + leaf_max;  // [leaf_max*8]
+    int* leaf_off = reinterpret_cast<int*>(scratch8 + leaf_max * 8);  // [leaf_max+1]
+    int* wcnt = leaf_off + leaf_max + 1;    // [8]
+    __shared__ long long u2_s;
+    const int tid = threadIdx.x;
+    const float inf = __builtin_inff();
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const float* prow = ps + row * s;
+        const int nv1 = block_compact(prow, g1, n1, A, wcnt);
+        const int nv2 = block_compact(prow, g2, n2, B, wcnt);
+        const bool tested = nv1 >= 3 && nv2 >= 3;   // block-uniform
+        if (!tested) {
+            if (tid == 0) {
+                o.tested[row] = 0; o.p[row] = 0.0;
+                if (o.z) o.z[row] = 0.0;
+                o.med1[row] = 0.f; o.med2[row] = 0.f; o.mean1[row] = 0.f; o.mean2[row] = 0.f; o.delta[row] = 0.f;
+            }
+            __syncthreads();
+            continue;
+        }
+        const float sum1 = block_pairwise_sum(A, nv1, leaf_off, leaf_sum, scratch8, leaf_max);
+        const float sum2 = block_pairwise_sum(B, nv2, leaf_off, leaf_sum, scratch8, leaf_max);
+        for (int i = nv1 + tid; i < P1; i += RB_THREADS) A[i] = inf;
+        for (int i = nv2 + tid; i < P2; i += RB_THREADS) B[i] = inf;
+        if (tid == 0) u2_s = 0;
+        __syncthreads();
+        // bitonic sort of both groups, sharing the barriers
+        const int PM = P1 > P2 ? P1 : P2;
+        for (int k = 2; k <= PM; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < PM; i += RB_THREADS) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const bool asc = (i & k) == 0;
+                        if (k <= P1 && l < P1) {
+                            const float x = A[i], y = A[l];
+                            if ((x > y) == asc) { A[i] = y; A[l] = x; }
+                        }
+                        if (k <= P2 && l < P2) {
+                            const float x = B[i], y = B[l];
+                            if ((x > y) == asc) { B[i] = y; B[l] = x; }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // 2U = sum_i lower_bound(B, a_i) + upper_bound(B, a_i)
+        long long local = 0;
+        for (int i = tid; i < nv1; i += RB_THREADS) {
+            const float ai = A[i];
+            int lo = 0, hi = nv2;
+            while (lo < hi) { const int m = (lo + hi) >> 1; if (B[m] < ai) lo = m + 1; else hi = m; }
+            const int lb = lo;
+            hi = nv2;
+            while (lo < hi) { const int m = (lo + hi) >> 1; if (B[m] <= ai) lo = m + 1; else hi = m; }
+            local += lb + lo;
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) local += __shfl_xor(local, ofs);
+        if ((tid & 63) == 0 && local) atomicAdd((unsigned long long*)&u2_s, (unsigned long long)local);
+        __syncthreads();
+        if (tid == 0) {
+            double z, p;
+            rs_finish(nv1, nv2, u2_s, z, p);
+            const float med1 = median_sorted(A, nv1), med2 = median_sorted(B, nv2);
+            o.tested[row] = 1; o.p[row] = p;
+            if (o.z) o.z[row] = z;
+            o.med1[row] = med1; o.med2[row] = med2;
+            o.mean1[row] = sum1 / (float)nv1; o.mean2[row] = sum2 / (float)nv2;
+            o.delta[row] = med1 - med2;
+        }
+        __syncthreads();
+    }
+}
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <int P1, int P2>
+int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2, RsOut o) {
+    const int stride = (n1 + n2) | 1;
+    int waves = 2;
+    const size_t lds = (size_t)waves * 64 * stride * 4;
+    int64_t groups = sd_ceil_div(n, 64);
+    int64_t blocks = sd_ceil_div(groups, waves);
+    const int64_t cap = (int64_t)ctx->n_cu * 16;
+    if (blocks > cap) blocks = cap;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_lane_kernel<P1, P2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ranksum_lane_kernel", (ranksum_lane_kernel<P1, P2>), dim3((unsigned)blocks), dim3(waves * 64), lds,
+              d_ps, n, s, gsel, n1, n2, stride, o);
+    return SDICE_OK;
+}
+
+template <int P1>
+int dispatch_lane_p2(sdice_ctx* ctx, int p2, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2,
+                     RsOut o) {
+    switch (p2) {
+        case 8: return launch_lane<P1, 8>(ctx, d_ps, n, s, gsel, n1, n2, o);
+        case 16: return launch_lane<P1, 16>(ctx, d_ps, n, s, gsel, n1, n2, o);
+        case 32: return launch_lane<P1, 32>(ctx, d_ps, n, s, gsel, n1, n2, o);
+        default: return launch_lane<P1, 64>(ctx, d_ps, n, s, gsel, n1, n2, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const float* d_ps, const int32_t* d_g1,
+                                 int32_t n1, const int32_t* d_g2, int32_t n2, uint8_t* d_tested, double* d_p,
+                                 double* d_z, float* d_med1, float* d_med2, float* d_mean1, float* d_mean2,
+                                 float* d_delta) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && s >= 0 && n1 >= 0 && n2 >= 0, "negative size");
+    if (n == 0) return SDICE_OK;
+    SD_ARG(d_tested && d_p && d_med1 && d_med2 && d_mean1 && d_mean2 && d_delta, "NULL output");
+    SD_ARG((n1 == 0 || d_g1) && (n2 == 0 || d_g2), "NULL group index");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_TRY(ctx->arena.reset(ctx->stream));
+    RsOut o{d_tested, d_p, d_z, d_med1, d_med2, d_mean1, d_mean2, d_delta};
+    if (n1 < 3 || n2 < 3) {
+        // no row can be tested (compareSampleSets.py:223)
+        SD_HIP(hipMemsetAsync(d_tested, 0, (size_t)n, ctx->stream));
+        SD_HIP(hipMemsetAsync(d_p, 0, (size_t)n * 8, ctx->stream));
+        if (d_z) SD_HIP(hipMemsetAsync(d_z, 0, (size_t)n * 8, ctx->stream));
+        float* f[5] = {d_med1, d_med2, d_mean1, d_mean2, d_delta};
+        for (auto q : f) SD_HIP(hipMemsetAsync(q, 0, (size_t)n * 4, ctx->stream));
+        return SDICE_OK;
+    }
+    SD_ARG(d_ps, "ps is NULL");
+    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block
+    const bool lane_ok = n1 <= 64 && n2 <= 64;
+    SD_ARG(variant != 1 || lane_ok, "lane variant needs n1, n2 <= 64");
+    if ((variant == 0 && lane_ok) || variant == 1) {
+        int32_t* gsel = (int32_t*)ctx->arena.alloc((size_t)(n1 + n2) * 4);
+        if (!gsel) return SDICE_ERR_NOMEM;
+        SD_HIP(hipMemcpyAsync(gsel, d_g1, (size_t)n1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        SD_HIP(hipMemcpyAsync(gsel + n1, d_g2, (size_t)n2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        int p1 = next_pow2(n1 < 8 ? 8 : n1), p2 = next_pow2(n2 < 8 ? 8 : n2);
+        switch (p1) {
+            case 8: return dispatch_lane_p2<8>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
+            case 16: return dispatch_lane_p2<16>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
+            case 32: return dispatch_lane_p2<32>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
+            default: return dispatch_lane_p2<64>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
+        }
+    }
+    const int P1 = next_pow2(n1), P2 = next_pow2(n2);
+    const int big = n1 > n2 ? n1 : n2;
+    const int leaf_max = big / 56 + 4;   // leaves of numpy's pairwise recursion hold 65..128 values
+    const size_t lds = (size_t)(P1 + P2 + leaf_max * 9) * 4 + (size_t)(leaf_max + 1 + 8) * 4;
+    SD_ARG(lds <= 150 * 1024, "groups too large for LDS");
+    int64_t blocks = n;
+    const int64_t cap = (int64_t)ctx->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_block_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ranksum_block_kernel", ranksum_block_kernel, dim3((unsigned)blocks), dim3(RB_THREADS), lds, d_ps, n,
+              (int)s, d_g1, (int)n1, d_g2, (int)n2, P1, P2, leaf_max, o);
+    return SDICE_OK;
+}
+
+extern "C" int sdice_ranksum(sdice_ctx* ctx, int64_t n, int32_t s, const float* ps, const int32_t* g1, int32_t n1,
+                             const int32_t* g2, int32_t n2, uint8_t* tested, double* p, double* z, float* med1,
+                             float* med2, float* mean1, float* mean2, float* delta) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && s >= 0 && n1 >= 0 && n2 >= 0, "negative size");
+    if (n == 0) return SDICE_OK;
+    SD_ARG(tested && p && med1 && med2 && mean1 && mean2 && delta, "NULL output");
+    for (int i = 0; i < n1; ++i) SD_ARG(g1[i] >= 0 && g1[i] < s, "g1 index out of range");
+    for (int i = 0; i < n2; ++i) SD_ARG(g2[i] >= 0 && g2[i] < s, "g2 index out of range");
+    float* d_ps = nullptr;
+    int32_t *dg1 = nullptr, *dg2 = nullptr;
+    uint8_t* dt = nullptr;
+    double *dp = nullptr, *dz = nullptr;
+    float* df = nullptr;
+    int rc = sdice_dmalloc(ctx, n * s * 4, (void**)&d_ps);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, (int64_t)n1 * 4, (void**)&dg1);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, (int64_t)n2 * 4, (void**)&dg2);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n, (void**)&dt);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * 8, (void**)&dp);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * 8, (void**)&dz);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * 4 * 5, (void**)&df);
+    if (rc == SDICE_OK) rc = sdice_h2d(ctx, d_ps, ps, n * s * 4);
+    if (rc == SDICE_OK && n1) rc = sdice_h2d(ctx, dg1, g1, (int64_t)n1 * 4);
+    if (rc == SDICE_OK && n2) rc = sdice_h2d(ctx, dg2, g2, (int64_t)n2 * 4);
+    if (rc == SDICE_OK)
+        rc = sdice_ranksum_dev(ctx, n, s, d_ps, dg1, n1, dg2, n2, dt, dp, dz, df, df + n, df + 2 * n, df + 3 * n,
+                               df + 4 * n);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, tested, dt, n);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, p, dp, n * 8);
+    if (rc == SDICE_OK && z) rc = sdice_d2h(ctx, z, dz, n * 8);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, med1, df, n * 4);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, med2, df + n, n * 4);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, mean1, df + 2 * n, n * 4);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, mean2, df + 3 * n, n * 4);
+    if (rc == SDICE_OK) rc = sdice_d2h(ctx, delta, df + 4 * n, n * 4);
+    sdice_dfree(ctx, d_ps); sdice_dfree(ctx, dg1); sdice_dfree(ctx, dg2); sdice_dfree(ctx, dt);
+    sdice_dfree(ctx, dp); sdice_dfree(ctx, dz); sdice_dfree(ctx, df);
+    return rc;
+}

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden
+fixtures generated from the reference.  Bars: clusters / integer sums / PS / medians / means
+bit-exact; z bit-exact; p-values within 1e-6 relative (north_star), tolerance written below.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+from splicedice_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P_RTOL = 1e-6          # north_star tolerance for p-values
+P_RTOL_TIGHT = 1e-9    # what the kernels actually reach on the KATs
+
+
+def _golden_arrays(golden_dir, tag):
+    return np.load(os.path.join(golden_dir, "arrays", f"cluster_psi_{tag}.npz"))
+
+
+# ------------------------------------------------------------------------------ clustering
+@pytest.mark.parametrize("tag", ["a", "b", "c", "dense"])
+def test_cluster_golden(ctx, golden_dir, tag):
+    z = _golden_arrays(golden_dir, tag)
+    row_of, row_ptr, col = ctx.cluster(z["chrom_rank"], z["left"], z["right"], z["strand"])
+    assert np.array_equal(row_of, z["row_of"])
+    assert np.array_equal(row_ptr, z["row_ptr"])
+    assert np.array_equal(col, z["col"])
+
+
+@pytest.mark.parametrize("n,seed,kw", [
+    (1, 1, {}), (2, 2, {}), (63, 3, {}), (64, 4, {}), (65, 5, {}), (1000, 6, {}),
+    (20000, 7, {}), (20000, 8, dict(n_chrom=1)), (30000, 9, dict(n_chrom=300, gene_spacing=3000)),
+    (5000, 10, dict(n_chrom=2, gene_spacing=50, len_span=100000)),   # very dense: long backward walks
+])
+def test_cluster_vs_oracle(ctx, n, seed, kw):
+    cr, left, right, strand = synth.make_junctions(n, seed, **kw)
+    want = O.cluster_csr(cr, left, right, strand)
+    got = ctx.cluster(cr, left, right, strand)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_cluster_touching_and_nested(ctx):
+    # (100,200)/(200,300) touch -> neighbours; (201,250) does not overlap (100,200)
+    cr = np.zeros(6, np.int32)
+    left = np.array([100, 200, 201, 100, 100, 150], np.int32)
+    right = np.array([200, 300, 250, 200, 1000, 160], np.int32)
+    strand = np.array([0, 0, 0, 1, 0, 0], np.int8)
+    want = O.cluster_csr(cr, left, right, strand)
+    got = ctx.cluster(cr, left, right, strand)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_cluster_empty_and_invalid(ctx):
+    e32 = np.zeros(0, np.int32)
+    row_of, row_ptr, col = ctx.cluster(e32, e32, e32, np.zeros(0, np.int8))
+    assert row_of.size == 0 and row_ptr.tolist() == [0] and col.size == 0
+    from splicedice_amd.engine import SdiceError
+    with pytest.raises(SdiceError):
+        ctx.cluster(np.zeros(2, np.int32), np.array([5, 1], np.int32), np.array([3, 2], np.int32), np.zeros(2, np.int8))
+
+
+# ------------------------------------------------------------------------------ PS
+@pytest.mark.parametrize("tag", ["a", "b", "c", "dense"])
+def test_ps_golden(ctx, golden_dir, tag):
+    z = _golden_arrays(golden_dir, tag)
+    ps, excl = ctx.ps(z["counts_rows"], z["row_ptr"], z["col"], want_excl=True)
+    assert ps.tobytes() == z["psi"].tobytes()          # bit-exact incl. NaN payload-insensitive check below
+    _, want_excl = O.calculate_psi_vectorised(z["counts_rows"], z["row_ptr"], z["col"])
+    assert np.array_equal(excl, want_excl)
+
+
+@pytest.mark.parametrize("n,s,seed", [(3000, 100, 1), (5000, 4, 2), (777, 7, 3), (300, 1000, 4), (2000, 1, 5),
+                                      (1500, 260, 6), (129, 36, 7), (40000, 16, 8)])
+def test_ps_vs_oracle(ctx, n, s, seed):
+    cr, left, right, strand = synth.make_junctions(n, seed, n_chrom=4)
+    _, row_ptr, col = O.cluster_csr(cr, left, right, strand) if n <= 5000 else ctx.cluster(cr, left, right, strand)
+    counts = synth.make_counts(n, s, seed + 50)
+    want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+    assert np.array_equal(excl, want_excl)
+    assert ps.view(np.uint32).tolist() == want_ps.view(np.uint32).tolist() or \
+        np.array_equal(np.isnan(ps), np.isnan(want_ps)) and np.array_equal(ps[~np.isnan(ps)], want_ps[~np.isnan(ps)])
+    only_ps = ctx.ps(counts, row_ptr, col)
+    assert np.array_equal(only_ps, ps, equal_nan=True)
+    only_excl = ctx.ps(counts, row_ptr, col, want_excl=True, want_ps=False)
+    assert np.array_equal(only_excl, excl)
+
+
+@pytest.mark.parametrize("lds,threads,tile_rows", [(8192, 64, 0), (32768, 256, 7), (65536, 1024, 0), (163840, 512, 0)])
+def test_ps_launch_shapes(ctx, lds, threads, tile_rows):
+    n, s = 4000, 100
+    cr, left, right, strand = synth.make_junctions(n, 21, n_chrom=3)
+    _, row_ptr, col = O.cluster_csr(cr, left, right, strand)
+    counts = synth.make_counts(n, s, 22)
+    want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    try:
+        ctx.set_param("ps.lds_bytes", lds)
+        ctx.set_param("ps.threads", threads)
+        ctx.set_param("ps.tile_rows", tile_rows)
+        ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+    finally:
+        ctx.set_param("ps.lds_bytes", 65536)
+        ctx.set_param("ps.threads", 512)
+        ctx.set_param("ps.tile_rows", 0)
+    assert np.array_equal(excl, want_excl)
+    assert np.array_equal(ps, want_ps, equal_nan=True)
+
+
+def test_ps_arbitrary_csr(ctx):
+    """Any valid CSR is accepted (e.g. parsed from a user's _allClusters.tsv): neighbours far
+    outside the tile window take the global-memory path; long lists overflow the LDS col stage."""
+    rng = np.random.default_rng(5)
+    n, s = 3000, 20
+    deg = rng.integers(0, 6, size=n)
+    deg[17] = 2500           # one huge list
+    deg[18] = 0
+    row_ptr = np.r_[0, np.cumsum(deg)].astype(np.int64)
+    col = rng.integers(0, n, size=int(row_ptr[-1])).astype(np.int32)
+    counts = synth.make_counts(n, s, 6)
+    want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+    assert np.array_equal(excl, want_excl)
+    assert np.array_equal(ps, want_ps, equal_nan=True)
+
+
+def test_ps_big_counts_and_zero(ctx):
+    # counts up to 2^24-1 with a long list: sums exceed 2^32; all-zero cluster -> NaN
+    n, s = 600, 8
+    counts = np.full((n, s), (1 << 24) - 1, np.int32)
+    counts[-3:] = 0
+    row_ptr = np.zeros(n + 1, np.int64)
+    row_ptr[1:] = 500
+    row_ptr[1:] = np.cumsum(np.r_[500, np.zeros(n - 4, np.int64), 2, 2, 2])
+    col = np.r_[np.arange(1, 501), [n - 2, n - 1], [n - 3, n - 1], [n - 3, n - 2]].astype(np.int32)
+    want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+    assert excl[0, 0] == 500 * ((1 << 24) - 1) and np.array_equal(excl, want_excl)
+    assert np.isnan(ps[-1]).all() and np.array_equal(ps, want_ps, equal_nan=True)
+
+
+def test_ps_empty(ctx):
+    ps = ctx.ps(np.zeros((0, 5), np.int32), np.zeros(1, np.int64), np.zeros(0, np.int32))
+    assert ps.shape == (0, 5)
+
+
+def test_mark_low_and_quantize(ctx):
+    rng = np.random.default_rng(3)
+    x = rng.random((50, 9)).astype(np.float32)
+    idx = np.array([0, 5, 449, 77], np.int64)
+    y = ctx.mark_low(x.copy(), idx)
+    assert np.isnan(y.ravel()[idx]).all() and np.isnan(y).sum() == 4
+    # '.3f' text round trip: every k/1000 neighbourhood + random values + specials
+    k = np.arange(0, 1001, dtype=np.float64) / 1000.0
+    base = k.astype(np.float32)
+    vals = np.concatenate([base, np.nextafter(base, np.float32(2)), np.nextafter(base, np.float32(-1)),
+                           (k + 0.0005).astype(np.float32), rng.random(20000).astype(np.float32),
+                           np.float32([np.nan, 0.0, 1.0, 0.0005, 0.9995, 0.99951, 1e-8])])
+    got = ctx.quantize3(vals)
+    want = O.quantize3(vals)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(O.quantize3_fast(vals), want, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------ rank-sum
+def _check_ranksum(got, want):
+    assert np.array_equal(got["tested"], want["tested"])
+    t = want["tested"].astype(bool)
+    for k in ("med1", "med2", "mean1", "mean2", "delta"):
+        assert np.array_equal(got[k][t], want[k][t]), k       # float32, bit-exact
+        assert not got[k][~t].any()
+    assert np.array_equal(got["z"][t], want["z"][t])          # z bit-exact (exact numerator, IEEE sqrt/div)
+    np.testing.assert_allclose(got["p"][t], want["p"][t], rtol=P_RTOL_TIGHT, atol=0)
+    assert P_RTOL_TIGHT <= P_RTOL
+
+
+def test_ranksum_kat(ctx, golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "kat_ranksums.json"))):
+        x, y = np.float32(c["x"]), np.float32(c["y"])
+        row = np.concatenate([x, y])[None, :]
+        for variant in ((0, 2) if max(len(x), len(y)) <= 64 else (2,)):
+            ctx.set_param("ranksum.variant", variant)
+            try:
+                r = ctx.ranksum(row, np.arange(len(x)), np.arange(len(x), len(x) + len(y)))
+            finally:
+                ctx.set_param("ranksum.variant", 0)
+            assert r["tested"][0] == 1
+            assert r["z"][0] == c["z"]
+            assert abs(r["p"][0] - c["p"]) <= P_RTOL_TIGHT * c["p"]
+            assert r["med1"][0] == np.float32(c["med1"]) and r["med2"][0] == np.float32(c["med2"])
+            assert r["mean1"][0] == np.float32(c["mean1"]) and r["mean2"][0] == np.float32(c["mean2"])
+
+
+@pytest.mark.parametrize("n1,n2,s,variant", [(50, 50, 100, 0), (50, 50, 100, 2), (3, 3, 6, 0), (3, 3, 6, 2),
+                                              (64, 64, 130, 0), (7, 33, 64, 0), (9, 17, 40, 0), (65, 10, 80, 0),
+                                              (500, 500, 1000, 0), (200, 130, 400, 0), (1500, 3, 1600, 0)])
+def test_ranksum_vs_oracle(ctx, n1, n2, s, variant):
+    n = 700 if s <= 200 else 60
+    ps = synth.make_ps_matrix(n, s, seed=n1 * 1000 + n2, nan_frac=0.1)
+    ps[0, :] = 0.5                 # all ties -> z = 0, p = 1
+    ps[1, :] = np.nan              # untested
+    ps[2, : s // 2] = np.nan
+    rng = np.random.default_rng(n1 + n2)
+    cols = rng.permutation(s)
+    g1 = np.sort(cols[:n1])        # table order (compareSampleSets.py:96-102)
+    g2 = np.sort(cols[n1:n1 + n2])
+    want = O.compare_rows(ps, g1, g2)
+    ctx.set_param("ranksum.variant", variant)
+    try:
+        got = ctx.ranksum(ps, g1, g2)
+    finally:
+        ctx.set_param("ranksum.variant", 0)
+    _check_ranksum(got, want)
+
+
+def test_ranksum_small_groups_untested(ctx):
+    ps = synth.make_ps_matrix(10, 8, seed=1)
+    got = ctx.ranksum(ps, [0, 1], [2, 3, 4, 5])
+    assert not got["tested"].any() and not got["p"].any()
+
+
+# ------------------------------------------------------------------------------ Fisher
+def test_fisher_kat(ctx, golden_dir):
+    kats = json.load(open(os.path.join(golden_dir, "kat_fisher.json")))
+    tables = np.array([t for t, _ in kats], np.int64)
+    want = np.array([p for _, p in kats])
+    got = ctx.fisher_tables(tables)
+    np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
+    ctx.set_param("fisher.table_max", 64)      # force the device-lgamma path for large margins
+    try:
+        got2 = ctx.fisher_tables(tables)
+    finally:
+        ctx.set_param("fisher.table_max", 1 << 20)
+    np.testing.assert_allclose(got2, want, rtol=P_RTOL_TIGHT, atol=0)
+
+
+@pytest.mark.parametrize("n,s,mean", [(40, 6, 20), (6, 31, 5), (3, 2, 100), (5, 12, 400)])
+def test_fisher_pairs_vs_scipy(ctx, n, s, mean):
+    incl = synth.make_counts(n, s, 77 + s, mean=mean)
+    excl = synth.make_counts(n, s, 78 + s, mean=mean * 4).astype(np.int64)
+    excl[0, :] = 0
+    want = O.fisher_pairs(incl, excl)
+    got = ctx.fisher_pairs(incl, excl)
+    np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
+
+
+# ------------------------------------------------------------------------------ BH
+@pytest.mark.parametrize("m", [1, 2, 255, 256, 257, 5000, 100000])
+def test_bh_vs_oracle(ctx, m):
+    rng = np.random.default_rng(m)
+    p = rng.random(m) ** 3
+    p[rng.random(m) < 0.1] = 1.0
+    if m > 10:
+        p[:5] = p[5]               # ties
+        p[7] = 0.0
+    want = O.bh_fdr(p)
+    got = ctx.bh(p)
+    np.testing.assert_allclose(got, want, rtol=1e-14, atol=0)
+    from scipy.stats import false_discovery_control
+    np.testing.assert_allclose(got, false_discovery_control(p, method="bh"), rtol=1e-12, atol=0)
+
+
+def test_bh_columns(ctx):
+    rng = np.random.default_rng(9)
+    p = rng.random((300, 15)) ** 2
+    np.testing.assert_allclose(ctx.bh_columns(p), O.bh_columns(p), rtol=1e-14, atol=0)
+
+
+# ------------------------------------------------------------------------------ device-resident pipeline
+def test_device_pipeline_matches_host_calls(ctx):
+    n, s = 6000, 40
+    cr, left, right, strand = synth.make_junctions(n, 91, n_chrom=5)
+    counts_in = synth.make_counts(n, s, 92)
+    row_of, row_ptr, col = ctx.cluster(cr, left, right, strand)
+    counts_rows = np.zeros_like(counts_in)
+    counts_rows[row_of] = counts_in
+    ps_host = ctx.ps(counts_rows, row_ptr, col)
+    d = {k: ctx.to_device(v) for k, v in dict(c=cr, l=left, r=right, s=strand).items()}
+    d_row_of, d_row_ptr = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    d_col, nnz = ctx.cluster_dev(d["c"], d["l"], d["r"], d["s"], d_row_of, d_row_ptr)
+    assert nnz == col.size and np.array_equal(d_col.to_host(), col)
+    d_counts, d_ps = ctx.to_device(counts_rows), ctx.empty((n, s), np.float32)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    ctx.ps_dev(d_counts, d_row_ptr, d_col, None, d_ps)
+    ctx.quantize3_dev(d_ps)
+    ctx.sync()
+    rep = ctx.prof_report()
+    ctx.prof_enable(False)
+    assert rep["ps_tile_kernel"][0] == 1 and rep["ps_tile_kernel"][1] > 0
+    assert np.array_equal(d_ps.to_host(), O.quantize3_fast(ps_host), equal_nan=True)
+    g1, g2 = np.arange(0, 20, dtype=np.int32), np.arange(20, 40, dtype=np.int32)
+    out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
+               med1=ctx.empty(n, np.float32), med2=ctx.empty(n, np.float32), mean1=ctx.empty(n, np.float32),
+               mean2=ctx.empty(n, np.float32), delta=ctx.empty(n, np.float32))
+    ctx.ranksum_dev(d_ps, ctx.to_device(g1), ctx.to_device(g2), out)
+    want = O.compare_rows(O.quantize3_fast(ps_host), g1, g2)
+    got = {k: v.to_host() for k, v in out.items()}
+    _check_ranksum(got, want)
+    # world-size-1 all-gather is a device copy
+    d_recv = ctx.empty(n, np.float64)
+    ctx.allgather_dev(out["p"], d_recv)
+    assert np.array_equal(d_recv.to_host(), got["p"])
