@@ -137,30 +137,44 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const uint64_t* __restr
                                                          const uint32_t* __restrict__ srow, int64_t n,
                                                          int64_t* __restrict__ deg /* by row (count pass) */,
                                                          const int64_t* __restrict__ row_ptr,
-                                                         int32_t* __restrict__ col) {
+                                                         int32_t* __restrict__ col,
+                                                         unsigned long long* __restrict__ reach_out) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint64_t seg_hi = ckL[p] & 0xffffffff00000000ull;
-    const uint64_t tgt_r = seg_hi | (ckR[p] & 0xffffffffull);  // later: ckL[q] <= seg|right_p
-    const uint64_t tgt_l = ckL[p];                             // earlier: ckR[q] >= seg|left_p
-    const uint32_t row = srow[p];
-    const int64_t ub = upper_bound_from(ckL, p, n, tgt_r);
-    int64_t cnt = 0;
-    int32_t* out = FILL ? col + row_ptr[row] : nullptr;
-    // earlier neighbours, most recent first
-    int64_t q = p - 1;
-    while (q >= 0 && pmax[q] >= tgt_l) {
-        if ((q & 63) == 63 && bmax[q >> 6] < tgt_l) { q -= 64; continue; }
-        if (ckR[q] >= tgt_l) {
-            if (FILL) out[cnt] = (int32_t)srow[q];
-            ++cnt;
+    unsigned reach = 0;
+    if (p < n) {
+        const uint64_t seg_hi = ckL[p] & 0xffffffff00000000ull;
+        const uint64_t tgt_r = seg_hi | (ckR[p] & 0xffffffffull);  // later: ckL[q] <= seg|right_p
+        const uint64_t tgt_l = ckL[p];                             // earlier: ckR[q] >= seg|left_p
+        const uint32_t row = srow[p];
+        const int64_t ub = upper_bound_from(ckL, p, n, tgt_r);
+        int64_t cnt = 0;
+        int32_t* out = FILL ? col + row_ptr[row] : nullptr;
+        // earlier neighbours, most recent first
+        int64_t q = p - 1;
+        int64_t far = p;   // farthest earlier neighbour
+        while (q >= 0 && pmax[q] >= tgt_l) {
+            if ((q & 63) == 63 && bmax[q >> 6] < tgt_l) { q -= 64; continue; }
+            if (ckR[q] >= tgt_l) {
+                if (FILL) out[cnt] = (int32_t)srow[q];
+                far = q;
+                ++cnt;
+            }
+            --q;
         }
-        --q;
+        if (FILL) {
+            for (int64_t t = p + 1; t < ub; ++t) out[cnt++] = (int32_t)srow[t];
+        } else {
+            deg[row] = cnt + (ub - p - 1);
+            // row order restricted to one (chrom,strand) segment equals sweep order, so the
+            // extreme neighbours in sweep order are the extreme ones in row order
+            if (far < p) reach = row - srow[far];
+            if (ub - 1 > p) reach = max(reach, srow[ub - 1] - row);
+        }
     }
-    if (FILL) {
-        for (int64_t t = p + 1; t < ub; ++t) out[cnt++] = (int32_t)srow[t];
-    } else {
-        deg[row] = cnt + (ub - p - 1);
+    if (!FILL) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) reach = max(reach, (unsigned)__shfl_xor((int)reach, o));
+        if ((threadIdx.x & 63) == 0 && reach) atomicMax(reach_out, (unsigned long long)reach);
     }
 }
 
@@ -175,6 +189,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
     SD_HIP(hipSetDevice(ctx->device));
     ctx->nnz = 0;
+    ctx->cluster_reach = 0;
     if (nnz_out) *nnz_out = 0;
     if (n == 0) {
         if (d_row_ptr) SD_HIP(hipMemsetAsync(d_row_ptr, 0, 8, ctx->stream));
@@ -200,7 +215,8 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
 
     // ---- keys + varying-bit masks
     ctx->h_pinned[0] = 0; ctx->h_pinned[1] = -1; ctx->h_pinned[2] = 0; ctx->h_pinned[3] = -1; ctx->h_pinned[4] = 0;
-    SD_HIP(hipMemcpyAsync(red, ctx->h_pinned, 40, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_pinned[5] = 0;   // red[5]: max row distance to a neighbour
+    SD_HIP(hipMemcpyAsync(red, ctx->h_pinned, 48, hipMemcpyHostToDevice, ctx->stream));
     {
         int64_t blocks = sd_ceil_div(n, 256);
         if (blocks > 1024) blocks = 1024;
@@ -245,11 +261,13 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     // ---- degrees -> row_ptr
     SD_HIP(hipMemsetAsync(deg + n, 0, 8, ctx->stream));
     SD_LAUNCH(ctx, "neighbours_count_kernel", (neighbours_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
-              pmax, bmax, srow, n, deg, (const int64_t*)nullptr, (int32_t*)nullptr);
+              pmax, bmax, srow, n, deg, (const int64_t*)nullptr, (int32_t*)nullptr, red + 5);
     SD_TRY(sd_exclusive_scan_i64(ctx, n + 1, deg, d_row_ptr, nullptr));
     SD_HIP(hipMemcpyAsync(ctx->h_pinned + 16, d_row_ptr + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipMemcpyAsync(ctx->h_pinned + 17, red + 5, 8, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t nnz = ctx->h_pinned[16];
+    ctx->cluster_reach = (int)ctx->h_pinned[17];
     if (nnz > ctx->col_cap) {
         if (ctx->d_col) (void)hipFree(ctx->d_col);
         ctx->d_col = nullptr;
@@ -265,7 +283,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     }
     if (nnz > 0)
         SD_LAUNCH(ctx, "neighbours_fill_kernel", (neighbours_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
-                  pmax, bmax, srow, n, (int64_t*)nullptr, (const int64_t*)d_row_ptr, ctx->d_col);
+                  pmax, bmax, srow, n, (int64_t*)nullptr, (const int64_t*)d_row_ptr, ctx->d_col, (unsigned long long*)nullptr);
     ctx->nnz = nnz;
     if (nnz_out) *nnz_out = nnz;
     return SDICE_OK;

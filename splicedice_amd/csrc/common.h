@@ -66,6 +66,7 @@ struct sdice_ctx {
     int32_t* d_col = nullptr;
     int64_t col_cap = 0;
     int64_t nnz = 0;
+    int cluster_reach = 0;   // max |row(neighbour) - row| of the last clustering (PS halo hint)
     int64_t* h_pinned = nullptr;  // small pinned buffer for scalar read-backs
 
     // log-factorial table of the Fisher kernel: lf[k] = lgamma(k+1)

@@ -8,17 +8,26 @@
 //
 // Design (HBM-bound, 8 algorithmic bytes per PS entry: 4 B count in + 4 B PS out):
 //   * one workgroup owns a tile of consecutive output rows x a chunk of columns;
-//   * it first walks the tile's CSR segment (staging the neighbour indices in LDS) to
-//     find the row window [wlo, whi) that holds every neighbour -- overlap clusters are
-//     gene sized, so the window is the tile plus a small halo;
-//   * the window of the count matrix is copied once, coalesced 16 B per lane, into LDS;
+//   * it stages the rows [r0 - halo, r1 + halo) of the count matrix into LDS with one
+//     coalesced 16 B/lane copy that depends on nothing but the tile index, so every load
+//     of the tile is in flight at once (overlap clusters are gene sized: the neighbours of
+//     a row lie a few rows away in (chrom,left,right,strand) order);
+//   * meanwhile the tile's CSR segment is read and turned into LDS byte offsets of the
+//     neighbour rows (or a sentinel for a neighbour outside the staged window);
 //   * every (row, 4-column) item then gathers its neighbour rows from LDS with
-//     ds_read_b128, accumulates in 64-bit integers, divides in float64 and stores a
-//     float4 -- each count is read from HBM once per tile (+halo) and each PS value is
-//     written once;
-//   * neighbours that fall outside the staged window (arbitrary user CSR, or a window
-//     larger than LDS) are read from global memory, so any valid CSR gives exact results.
+//     ds_read_b128 and stores a float4 -- each count is read from HBM once per tile
+//     (+halo, which is an L2 hit) and each PS value is written once;
+//   * a neighbour outside the window (arbitrary user CSR, unusually long junction) is read
+//     from global memory instead, so ANY valid CSR gives exact results; the halo only
+//     decides how often that slower path runs.
+// Arithmetic: sums are exact integers.  When a tile's bound (max count) * (max degree + 1)
+// is below 2^24, sums are kept in 32 bits and the quotient is one IEEE float32 division:
+// both operands are then exact float32 values and a correctly rounded float32 quotient of
+// two such integers equals float32(float64 quotient) (a double rounding could only differ
+// if the exact quotient were within 2^-53 of a float32 midpoint, impossible for a
+// denominator below 2^24).  Otherwise 64-bit sums and the float64 division are used.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -31,56 +40,112 @@ struct PsArgs {
     int64_t n;
     int s;
     int tile_rows;   // output rows per tile
+    int halo;        // extra rows staged on each side of the tile
     int chunk_cols;  // columns per chunk == LDS row stride (multiple of VEC)
-    int win_cap;     // LDS window capacity in rows
-    int col_cap;     // LDS capacity for staged neighbour indices (ints)
+    int col_cap;     // LDS capacity for staged neighbour offsets (ints)
     int n_tiles;
     int tiles_per_xcd;  // 0 = no remap
 };
 
 template <int VEC> struct Vt;
-template <> struct Vt<4> { typedef int4 I; typedef float4 F; };
-template <> struct Vt<1> { typedef int I; typedef float F; };
+template <> struct Vt<4> { typedef int4 I; };
+template <> struct Vt<1> { typedef int I; };
 
-__device__ __forceinline__ float ps_value(unsigned incl, unsigned long long excl) {
+__device__ __forceinline__ float ps_value64(unsigned incl, unsigned long long excl) {
     // float32(float64(incl) / float64(incl + excl)), SPLICEDICE.py:306; 0/0 -> NaN
     const double a = (double)incl;
     const double t = a + (double)excl;
     return (float)(a / t);
 }
+__device__ __forceinline__ float ps_value32(unsigned incl, unsigned excl) {
+    // valid when incl + excl < 2^24 (see header): one correctly rounded float32 division
+    return (float)incl / (float)(incl + excl);
+}
 
-__device__ __forceinline__ void acc_add(unsigned long long (&acc)[4], const int4& v) {
+__device__ __forceinline__ unsigned vmax(const int4& v) {
+    return max(max((unsigned)v.x, (unsigned)v.y), max((unsigned)v.z, (unsigned)v.w));
+}
+__device__ __forceinline__ unsigned vmax(const int& v) { return (unsigned)v; }
+
+template <typename ACC> __device__ __forceinline__ void acc_add(ACC (&acc)[4], const int4& v) {
     acc[0] += (unsigned)v.x; acc[1] += (unsigned)v.y; acc[2] += (unsigned)v.z; acc[3] += (unsigned)v.w;
 }
-__device__ __forceinline__ void acc_add(unsigned long long (&acc)[1], const int& v) { acc[0] += (unsigned)v; }
+template <typename ACC> __device__ __forceinline__ void acc_add(ACC (&acc)[1], const int& v) { acc[0] += (unsigned)v; }
 
-__device__ __forceinline__ void store_ps(float* p, const int4& own, const unsigned long long (&acc)[4]) {
-    float4 o;
-    o.x = ps_value((unsigned)own.x, acc[0]);
-    o.y = ps_value((unsigned)own.y, acc[1]);
-    o.z = ps_value((unsigned)own.z, acc[2]);
-    o.w = ps_value((unsigned)own.w, acc[3]);
-    *reinterpret_cast<float4*>(p) = o;
+__device__ __forceinline__ unsigned comp(const int4& v, int q) { return (unsigned)(q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w); }
+__device__ __forceinline__ unsigned comp(const int& v, int) { return (unsigned)v; }
+
+template <int VEC> __device__ __forceinline__ void store_f(float* p, const float (&o)[VEC]);
+template <> __device__ __forceinline__ void store_f<4>(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
 }
-__device__ __forceinline__ void store_ps(float* p, const int& own, const unsigned long long (&acc)[1]) {
-    *p = ps_value((unsigned)own, acc[0]);
+template <> __device__ __forceinline__ void store_f<1>(float* p, const float (&o)[1]) { *p = o[0]; }
+
+template <int VEC, typename ACC> __device__ __forceinline__ void store_excl(int64_t* p, const ACC (&acc)[VEC]) {
+    if (VEC == 4) {
+        longlong2 a, b;
+        a.x = (long long)acc[0]; a.y = (long long)acc[1]; b.x = (long long)acc[VEC - 2]; b.y = (long long)acc[VEC - 1];
+        reinterpret_cast<longlong2*>(p)[0] = a;
+        reinterpret_cast<longlong2*>(p)[1] = b;
+    } else {
+        *p = (int64_t)acc[0];
+    }
 }
-__device__ __forceinline__ void store_excl(int64_t* p, const unsigned long long (&acc)[4]) {
-    longlong2 a, b;
-    a.x = (long long)acc[0]; a.y = (long long)acc[1]; b.x = (long long)acc[2]; b.y = (long long)acc[3];
-    reinterpret_cast<longlong2*>(p)[0] = a;
-    reinterpret_cast<longlong2*>(p)[1] = b;
+
+// Gather + divide one (row, vector) item.  FAST: 32-bit sums + float32 division; returns false
+// (nothing stored) if a neighbour read through the global fallback breaks the tile's bound.
+template <int VEC, bool FAST, bool WEXCL, bool WPS>
+__device__ __forceinline__ bool ps_item(const PsArgs& a, const char* tileB, const int* colL, bool col_in_lds,
+                                        int64_t kbase, int k0, int k1, int slo, int wrows, int ldw, int c0, int cvec,
+                                        int own_row, int64_t out_index, unsigned thr) {
+    typedef typename Vt<VEC>::I VI;
+    typedef typename std::conditional<FAST, unsigned, unsigned long long>::type ACC;
+    ACC acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0;
+    bool ok = true;
+    const int cbytes = cvec * 4;
+    for (int k = k0; k < k1; ++k) {
+        int off;
+        if (col_in_lds) {
+            off = colL[k];
+        } else {
+            const int j = a.col[kbase + k];
+            const unsigned rel = (unsigned)(j - slo);
+            off = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
+        }
+        VI v;
+        if (off >= 0) {
+            v = *reinterpret_cast<const VI*>(tileB + off + cbytes);
+        } else {
+            const int j = -1 - off;
+            v = *reinterpret_cast<const VI*>(a.counts + (int64_t)j * a.s + c0 + cvec);
+            if (FAST && vmax(v) > thr) ok = false;
+        }
+        acc_add(acc, v);
+    }
+    if (FAST && !ok) return false;
+    const VI own = *reinterpret_cast<const VI*>(tileB + own_row * ldw * 4 + cbytes);
+    if (WPS) {
+        float o[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+            o[q] = FAST ? ps_value32(comp(own, q), (unsigned)acc[q]) : ps_value64(comp(own, q), (unsigned long long)acc[q]);
+        store_f<VEC>(a.ps + out_index, o);
+    }
+    if (WEXCL) store_excl<VEC, ACC>(a.excl + out_index, acc);
+    return true;
 }
-__device__ __forceinline__ void store_excl(int64_t* p, const unsigned long long (&acc)[1]) { *p = (int64_t)acc[0]; }
 
 template <int VEC, bool WEXCL, bool WPS>
 __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     typedef typename Vt<VEC>::I VI;
     extern __shared__ int4 smem4[];
+    const int win_cap = a.tile_rows + 2 * a.halo;
     int* tileL = reinterpret_cast<int*>(smem4);
-    int* colL = tileL + (size_t)a.win_cap * a.chunk_cols;
+    int* colL = tileL + (size_t)win_cap * a.chunk_cols;
     int* rpL = colL + a.col_cap;
-    int* red = rpL + a.tile_rows + 1;  // [0..15] per-wave min, [16..31] per-wave max
+    unsigned* red = reinterpret_cast<unsigned*>(rpL + a.tile_rows + 1);  // [0] max count, [1] max degree
 
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -97,84 +162,87 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     const int ldw = a.chunk_cols;
     const int64_t r0 = (int64_t)tile * a.tile_rows;
     const int nr = (int)min((int64_t)a.tile_rows, a.n - r0);
-    const int64_t kbase = a.row_ptr[r0];
-    const int64_t nk = a.row_ptr[r0 + nr] - kbase;
-    const bool col_in_lds = nk <= (int64_t)a.col_cap;
-
-    // ---- phase A: CSR segment -> LDS, neighbour window by min/max reduction
-    for (int i = tid; i <= nr; i += T) rpL[i] = (int)(a.row_ptr[r0 + i] - kbase);
-    int lmin = (int)r0, lmax = (int)r0 + nr - 1;
-    for (int64_t k = tid; k < nk; k += T) {
-        const int j = a.col[kbase + k];
-        if (col_in_lds) colL[k] = j;
-        lmin = min(lmin, j);
-        lmax = max(lmax, j);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lmin = min(lmin, __shfl_xor(lmin, o));
-        lmax = max(lmax, __shfl_xor(lmax, o));
-    }
-    if ((tid & 63) == 0) { red[tid >> 6] = lmin; red[16 + (tid >> 6)] = lmax; }
-    __syncthreads();
-    const int nw = (T + 63) >> 6;
-    int wlo = red[0], whi = red[16];
-    for (int w = 1; w < nw; ++w) { wlo = min(wlo, red[w]); whi = max(whi, red[16 + w]); }
-    whi += 1;
-    int slo = wlo, shi = whi;
-    if (whi - wlo > a.win_cap) {
-        const int extra = a.win_cap - nr;
-        slo = max(wlo, (int)r0 - extra / 2);
-        shi = slo + a.win_cap;
-        if (shi > whi) { shi = whi; slo = max(wlo, shi - a.win_cap); }
-    }
+    const int slo = (int)max((int64_t)0, r0 - a.halo);
+    const int shi = (int)min(a.n, r0 + nr + a.halo);
     const int wrows = shi - slo;
+    if (tid < 2) red[tid] = 0u;
 
-    // ---- phase B: stage rows [slo, shi) x cols [c0, c0+cwc) into LDS (coalesced, 16 B/lane)
+    // ---- CSR row pointers of the tile (their loads go out first, the data loads right behind)
+    int64_t rp_mine[2];
+    rp_mine[0] = (tid <= nr) ? a.row_ptr[r0 + tid] : 0;
+    rp_mine[1] = (tid + T <= nr) ? a.row_ptr[r0 + tid + T] : 0;
+    const int64_t kbase = a.row_ptr[r0];
+
+    // ---- stage rows [slo, shi) x cols [c0, c0+cwc) into LDS, 16 B per lane, 4 loads in flight
+    unsigned cmax = 0;
     {
         const int total = wrows * V;
         if (cwc == a.s) {
             const VI* g = reinterpret_cast<const VI*>(a.counts + (int64_t)slo * a.s);
             VI* l = reinterpret_cast<VI*>(tileL);
-            for (int i = tid; i < total; i += T) l[i] = g[i];
+            int i = tid;
+            for (; i + 3 * T < total; i += 4 * T) {
+                const VI v0 = g[i], v1 = g[i + T], v2 = g[i + 2 * T], v3 = g[i + 3 * T];
+                l[i] = v0; l[i + T] = v1; l[i + 2 * T] = v2; l[i + 3 * T] = v3;
+                cmax = max(max(cmax, vmax(v0)), max(vmax(v1), max(vmax(v2), vmax(v3))));
+            }
+            for (; i < total; i += T) { const VI v = g[i]; l[i] = v; cmax = max(cmax, vmax(v)); }
         } else {
             int rr = tid / V, cc = tid - rr * V;
             const int dr = T / V, dc = T - dr * V;
             for (int i = tid; i < total; i += T) {
-                *reinterpret_cast<VI*>(tileL + rr * ldw + cc * VEC) =
-                    *reinterpret_cast<const VI*>(a.counts + (int64_t)(slo + rr) * a.s + c0 + cc * VEC);
+                const VI v = *reinterpret_cast<const VI*>(a.counts + (int64_t)(slo + rr) * a.s + c0 + cc * VEC);
+                *reinterpret_cast<VI*>(tileL + rr * ldw + cc * VEC) = v;
+                cmax = max(cmax, vmax(v));
                 cc += dc; rr += dr;
                 if (cc >= V) { cc -= V; rr += 1; }
             }
         }
     }
+    // ---- CSR segment -> LDS: relative row pointers, neighbour LDS offsets, max degree
+    const int64_t nk = a.row_ptr[r0 + nr] - kbase;
+    const bool col_in_lds = nk <= (int64_t)a.col_cap;
+    unsigned dmax = 0;
+    if (tid <= nr) rpL[tid] = (int)(rp_mine[0] - kbase);
+    if (tid + T <= nr) rpL[tid + T] = (int)(rp_mine[1] - kbase);
+    for (int i = tid + 2 * T; i <= nr; i += T) rpL[i] = (int)(a.row_ptr[r0 + i] - kbase);
+    if (col_in_lds) {
+        for (int k = tid; k < (int)nk; k += T) {
+            const int j = a.col[kbase + k];
+            const unsigned rel = (unsigned)(j - slo);
+            colL[k] = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o));
+    if ((tid & 63) == 0) atomicMax(&red[0], cmax);
     __syncthreads();
+    for (int i = tid; i < nr; i += T) dmax = max(dmax, (unsigned)(rpL[i + 1] - rpL[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o));
+    if ((tid & 63) == 0) atomicMax(&red[1], dmax);
+    __syncthreads();
+    const unsigned tile_cmax = red[0], tile_dmax = red[1];
+    const unsigned thr = 0xFFFFFFu / (tile_dmax + 1u);   // per-count bound keeping incl+excl < 2^24
+    const bool fast = tile_cmax <= thr;                   // block-uniform
 
-    // ---- phase C: per (row, vector) item: gather neighbours, divide, store
+    // ---- per (row, vector) item: gather neighbours from LDS, divide, store
     {
+        const char* tileB = reinterpret_cast<const char*>(tileL);
         const int items = nr * V;
         int ri = tid / V, c = tid - ri * V;
         const int dr = T / V, dc = T - dr * V;
         const int own_base = (int)(r0 - slo);
         for (int it = tid; it < items; it += T) {
-            unsigned long long acc[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] = 0ull;
             const int k0 = rpL[ri], k1 = rpL[ri + 1];
-            for (int k = k0; k < k1; ++k) {
-                const int j = col_in_lds ? colL[k] : a.col[kbase + k];
-                const unsigned rel = (unsigned)(j - slo);
-                VI v;
-                if (rel < (unsigned)wrows)
-                    v = *reinterpret_cast<const VI*>(tileL + rel * ldw + c * VEC);
-                else
-                    v = *reinterpret_cast<const VI*>(a.counts + (int64_t)j * a.s + c0 + c * VEC);
-                acc_add(acc, v);
-            }
-            const VI own = *reinterpret_cast<const VI*>(tileL + (own_base + ri) * ldw + c * VEC);
             const int64_t o = (r0 + ri) * a.s + c0 + c * VEC;
-            if (WPS) store_ps(a.ps + o, own, acc);
-            if (WEXCL) store_excl(a.excl + o, acc);
+            bool done = false;
+            if (fast)
+                done = ps_item<VEC, true, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0,
+                                                      c * VEC, own_base + ri, o, thr);
+            if (!done)
+                ps_item<VEC, false, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
+                                                own_base + ri, o, thr);
             c += dc; ri += dr;
             if (c >= V) { c -= V; ri += 1; }
         }
@@ -239,10 +307,10 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     const bool aligned = ((uintptr_t)d_counts % 16 == 0) && (!d_ps || (uintptr_t)d_ps % 16 == 0) &&
                          (!d_excl || (uintptr_t)d_excl % 16 == 0);
     const int vec = (s % 4 == 0 && aligned) ? 4 : 1;
-    int64_t lds = ctx->param("ps.lds_bytes", 64 * 1024);
+    int64_t lds = ctx->param("ps.lds_bytes", 80 * 1024);   // two workgroups per CU (160 KiB LDS)
     if (lds > 160 * 1024) lds = 160 * 1024;
     if (lds < 8 * 1024) lds = 8 * 1024;
-    int threads = (int)ctx->param("ps.threads", 512);
+    int threads = (int)ctx->param("ps.threads", 1024);
     threads = (threads / 64) * 64;
     if (threads < 64) threads = 64;
     if (threads > 1024) threads = 1024;
@@ -255,22 +323,37 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     if (vec == 4) cw = (cw / 4) * 4;
     if (cw < vec) cw = vec;
 
-    const int64_t L = lds / 4 - 64;  // ints available (64 reserved for the reduction scratch)
+    // LDS budget (ints): (R + 2H) * cw window + 16 R staged neighbour offsets + (R + 1) row
+    // pointers + 8 scratch
+    const int64_t L = lds / 4 - 16;
+    int64_t H = ctx->param("ps.halo_rows", -1);
+    if (H < 0) {
+        // rows further than the halo are still summed exactly (global-memory path); 16 rows cover
+        // >99.9 % of the neighbours of gene-shaped data, less if the clustering saw a smaller reach
+        H = 16;
+        if (d_col != nullptr && d_col == ctx->d_col && ctx->cluster_reach > 0 && ctx->cluster_reach < H)
+            H = ctx->cluster_reach;
+    }
     int64_t R = ctx->param("ps.tile_rows", 0);
-    if (R <= 0) R = (int64_t)(L / (1.5 * cw + 17.0));
+    if (R <= 0) R = (L - 2 * H * cw) / (cw + 17);
+    if (R > 2 * threads) R = 2 * threads;   // the kernel keeps two row pointers per thread in registers
+    while (H > 0 && (R < 8 || (R + 2 * H) * cw + 17 * R > L)) {
+        // window does not fit: shrink the halo first (misses fall back to global loads), then the tile
+        H = H / 2;
+        if (ctx->param("ps.tile_rows", 0) <= 0) R = (L - 2 * H * cw) / (cw + 17);
+        if (R > 2 * threads) R = 2 * threads;
+    }
     if (R < 1) R = 1;
-    // shrink the tile until a window of at least R rows fits
-    while (R > 1 && (L - 17 * R - 1) / cw < R) R = R * 3 / 4;
-    int64_t win = (L - 17 * R - 1) / cw;
-    SD_ARG(win >= R && win >= 1, "row chunk does not fit LDS; lower ps.chunk_cols");
+    while (R > 1 && (R + 2 * H) * cw + 17 * R > L) R -= 1;
+    SD_ARG((R + 2 * H) * cw + 17 * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
     if (R > n) { R = n; }
 
     PsArgs a;
     a.counts = d_counts; a.row_ptr = d_row_ptr; a.col = d_col; a.excl = d_excl; a.ps = d_ps;
     a.n = n; a.s = s;
     a.tile_rows = (int)R;
+    a.halo = (int)H;
     a.chunk_cols = cw;
-    a.win_cap = (int)win;
     a.col_cap = (int)(16 * R);
     a.n_tiles = (int)sd_ceil_div(n, R);
     const int n_chunks = (int)sd_ceil_div(s, cw);

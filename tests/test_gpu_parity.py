@@ -92,8 +92,9 @@ def test_ps_vs_oracle(ctx, n, s, seed):
     assert np.array_equal(only_excl, excl)
 
 
-@pytest.mark.parametrize("lds,threads,tile_rows", [(8192, 64, 0), (32768, 256, 7), (65536, 1024, 0), (163840, 512, 0)])
-def test_ps_launch_shapes(ctx, lds, threads, tile_rows):
+@pytest.mark.parametrize("lds,threads,tile_rows,halo", [(8192, 64, 0, -1), (32768, 256, 7, 0), (65536, 1024, 0, 3),
+                                                         (163840, 512, 0, 40), (81920, 1024, 0, 1)])
+def test_ps_launch_shapes(ctx, lds, threads, tile_rows, halo):
     n, s = 4000, 100
     cr, left, right, strand = synth.make_junctions(n, 21, n_chrom=3)
     _, row_ptr, col = O.cluster_csr(cr, left, right, strand)
@@ -103,11 +104,13 @@ def test_ps_launch_shapes(ctx, lds, threads, tile_rows):
         ctx.set_param("ps.lds_bytes", lds)
         ctx.set_param("ps.threads", threads)
         ctx.set_param("ps.tile_rows", tile_rows)
+        ctx.set_param("ps.halo_rows", halo)
         ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
     finally:
-        ctx.set_param("ps.lds_bytes", 65536)
-        ctx.set_param("ps.threads", 512)
+        ctx.set_param("ps.lds_bytes", 81920)
+        ctx.set_param("ps.threads", 1024)
         ctx.set_param("ps.tile_rows", 0)
+        ctx.set_param("ps.halo_rows", -1)
     assert np.array_equal(excl, want_excl)
     assert np.array_equal(ps, want_ps, equal_nan=True)
 
