@@ -1,0 +1,379 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X splicedice hot path (driver contract: one JSON line on rank 0).
+
+    python bench.py --gpus 1 --steps K --warmup W              # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W  # N ranks, one per GPU
+
+Workloads (BASELINE.json configs):
+  quant   (default; config 2) : 1M junctions x 100 samples int32 counts resident in HBM.
+          One step = the whole quant device path on the rank's junction shard:
+          sdice_cluster_dev (sort + overlap lists) + sdice_ps_dev (exclusion sums + PS).
+          metric = PS-matrix entries/s.
+  compare (config 3)          : 1M rows x (50 v 50) float32 PS table; step = sdice_ranksum_dev
+          + sdice_bh_dev; metric = junction tests/s.
+  pairwise (config 4 per-GPU shard) : 25k junctions x 200 samples; step = exclusion sums +
+          sdice_fisher_pairs_dev; metric = p-values/s.
+
+Multi-GPU: the junction axis is sharded, every rank owns the junctions of its own chromosome
+group (zero halo, no data-path collective inside a step -> weak scaling).  torch.distributed
+(gloo) is used only as the control plane (barrier, max-over-ranks); the data-plane collective
+is the library's own RCCL all-gather, exercised after the timed region and reported in
+"allgather" (it reassembles the per-junction result tables, not the PS matrix -- DESIGN.md).
+
+The timed region is bracketed by barrier + device sync on both sides; rank 0 prints the
+max-over-ranks time.  "roofline" is for the dominant kernel, timed with HIP events on the
+library's stream inside the timed region (profiling mode 2 records only that kernel).
+"cpu_baseline" times the oracle's loop-for-loop restatement of the reference on a bounded
+sample, on rank 0 at N=1 only; it is a reported baseline, never the thing measured above.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# Load the HIP library before anything that could pull in another HIP runtime.
+from splicedice_amd.engine import Context  # noqa: E402
+from splicedice_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["quant", "compare", "pairwise"], default="quant")
+    ap.add_argument("--n", type=int, default=0, help="junctions per GPU (default: the BASELINE config)")
+    ap.add_argument("--s", type=int, default=0, help="samples (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="junctions in the CPU-baseline sample")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+class Dist:
+    """Control plane only: rendezvous, barrier, max over ranks, one small broadcast."""
+
+    def __init__(self, world):
+        self.world = world
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.pg = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+            assert dist.get_world_size() == world, (dist.get_world_size(), world)
+            self.pg = dist
+
+    def barrier(self):
+        if self.pg:
+            self.pg.barrier()
+
+    def max(self, x):
+        if not self.pg:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return float(t[0])
+
+    def bcast_bytes(self, b, n):
+        if not self.pg:
+            return b
+        import torch
+        t = torch.frombuffer(bytearray(b if self.rank == 0 else bytes(n)), dtype=torch.uint8).clone()
+        self.pg.broadcast(t, src=0)
+        return bytes(t.numpy().tobytes())
+
+    def close(self):
+        if self.pg:
+            self.pg.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------ workloads
+class QuantWorkload:
+    name = "quant: cluster + PS"
+    metric = "PS-matrix entries/sec (junctions x samples)"
+    unit = "entries/s"
+    dtype = "int32 counts -> f32 PS"
+    kernel = "ps_tile_kernel"
+
+    def __init__(self, ctx, rank, n, s):
+        self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
+        n, s = self.n, self.s
+        t = time.time()
+        self.junc = synth.make_junctions(n, 2 + 1000 * rank)          # this rank's chromosome group
+        self.counts_host_seed = 20 + 1000 * rank
+        counts = synth.make_counts(n, s, self.counts_host_seed)       # rows already in output order
+        self.gen_s = time.time() - t
+        self.d_j = [ctx.to_device(x) for x in self.junc]
+        self.d_row_of, self.d_row_ptr = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+        self.d_counts = ctx.to_device(counts)
+        self.sample_counts = counts[: min(n, 200_000)].copy()
+        del counts
+        self.d_ps = ctx.empty((n, s), np.float32)
+        self.nnz = 0
+        self.units = n * s
+        # algorithmic bytes per launch of the dominant kernel: 4 B count + 4 B PS per entry
+        self.alg_bytes = 8.0 * n * s
+
+    def step(self):
+        self.d_col, self.nnz = self.ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr)
+        self.ctx.ps_dev(self.d_counts, self.d_row_ptr, self.d_col, None, self.d_ps)
+
+    def describe(self):
+        return {"workload": f"quant {self.n} junctions x {self.s} samples per GPU (BASELINE config 2), cluster+PS",
+                "junctions_per_gpu": self.n, "samples": self.s, "avg_overlap_degree": round(self.nnz / self.n, 2)}
+
+    def verify(self):
+        """PS of the first rows against the oracle (same CSR prefix, vectorised restatement)."""
+        from oracle import oracle_np as O
+        big = self.sample_counts.shape[0]            # rows whose counts are kept on the host
+        rp = self.d_row_ptr.to_host()[: big + 1]
+        col = self.d_col.to_host()[: int(rp[-1])]
+        inside = np.minimum.reduceat(np.r_[col, 0] < big, np.minimum(rp[:-1], col.size)) | (np.diff(rp) == 0)
+        want, _ = O.calculate_psi_vectorised(self.sample_counts, rp, np.minimum(col, big - 1))
+        got = self.d_ps.to_host()[:big]
+        rows = np.flatnonzero(inside)[:50_000]       # rows with every neighbour among the kept rows
+        return bool(np.array_equal(got[rows], want[rows], equal_nan=True)), int(rows.size)
+
+    def cpu_baseline(self, sample):
+        """Loop-for-loop restatement (oracle) of getClusters + calculatePsi on `sample` junctions, 1 core."""
+        from oracle import oracle_np as O
+        m = min(self.n, sample or 40_000)
+        cr, l, r, st = (x[:m] for x in self.junc)
+        counts = self.sample_counts[:m]
+        t = time.time()
+        row_of, row_ptr, col = O.cluster_csr(cr, l, r, st)
+        O.calculate_psi(counts, row_ptr, col)
+        dt = time.time() - t
+        return {"value": m * self.s / dt, "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": f"first {m} junctions x {self.s} samples: oracle get_clusters + calculate_psi "
+                          f"(Python loops + numpy as the reference), {dt:.1f} s"}
+
+
+class CompareWorkload:
+    name = "compare_sample_sets: rank-sum + BH"
+    metric = "junction rank-sum tests/sec (50 v 50)"
+    unit = "rows/s"
+    dtype = "f32 PS -> f64 p"
+    kernel = "ranksum_lane_kernel"
+
+    def __init__(self, ctx, rank, n, s):
+        self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
+        n, s = self.n, self.s
+        t = time.time()
+        ps = synth.make_ps_matrix(n, s, 3 + 1000 * rank)
+        self.gen_s = time.time() - t
+        self.g1 = np.arange(0, s // 2, dtype=np.int32)
+        self.g2 = np.arange(s // 2, s, dtype=np.int32)
+        self.sample_ps = ps[: min(n, 100_000)].copy()
+        self.d_ps = ctx.to_device(ps)
+        del ps
+        self.d_g1, self.d_g2 = ctx.to_device(self.g1), ctx.to_device(self.g2)
+        self.out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
+                        med1=ctx.empty(n, np.float32), med2=ctx.empty(n, np.float32), mean1=ctx.empty(n, np.float32),
+                        mean2=ctx.empty(n, np.float32), delta=ctx.empty(n, np.float32))
+        self.d_q = ctx.empty(n, np.float64)
+        self.units = n
+        if max(self.g1.size, self.g2.size) > 64:
+            self.kernel = "ranksum_block_kernel"
+        self.alg_bytes = (4.0 * s + 28.0) * n          # 4*S_sel + 28 B per junction
+
+    def step(self):
+        self.ctx.ranksum_dev(self.d_ps, self.d_g1, self.d_g2, self.out)
+        self.ctx.bh_dev(self.out["p"], self.d_q)       # BH over all rows (untested rows carry p = 0 here)
+
+    def describe(self):
+        return {"workload": f"compare_sample_sets {self.n} junctions, {self.g1.size} v {self.g2.size} (BASELINE config 3), "
+                            f"rank-sum + BH", "junctions_per_gpu": self.n, "samples": self.s}
+
+    def verify(self):
+        from oracle import oracle_np as O
+        m = min(self.n, 3000)
+        want = O.compare_rows(self.sample_ps[:m], self.g1, self.g2)
+        got = {k: v.to_host()[:m] for k, v in self.out.items()}
+        t = want["tested"].astype(bool)
+        ok = np.array_equal(got["tested"], want["tested"]) and np.array_equal(got["z"][t], want["z"][t]) \
+            and np.allclose(got["p"][t], want["p"][t], rtol=1e-9, atol=0) \
+            and all(np.array_equal(got[k][t], want[k][t]) for k in ("med1", "med2", "mean1", "mean2", "delta"))
+        return bool(ok), m
+
+    def cpu_baseline(self, sample):
+        from oracle import oracle_np as O
+        m = min(self.n, sample or 40_000)
+        t = time.time()
+        r = O.compare_rows(self.sample_ps[:m], self.g1, self.g2)
+        O.bh_fdr(r["p"][r["tested"].astype(bool)])
+        dt = time.time() - t
+        return {"value": m / dt, "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": f"first {m} rows: oracle compare_rows (scipy.stats.ranksums + np.median/np.mean per row, "
+                          f"as compareSampleSets.py:216-232) + BH, {dt:.1f} s"}
+
+
+class PairwiseWorkload:
+    name = "pairwise: exclusion sums + Fisher exact"
+    metric = "Fisher exact p-values/sec (all sample pairs)"
+    unit = "p-values/s"
+    dtype = "int64 tables -> f64 p"
+    kernel = "fisher_pairs_kernel"
+
+    def __init__(self, ctx, rank, n, s):
+        # config 4 is 200k junctions x 200 samples sharded over 8 GPUs -> 25k junctions per GPU
+        self.ctx, self.n, self.s = ctx, n or 25_000, s or 200
+        n, s = self.n, self.s
+        t = time.time()
+        self.junc = synth.make_junctions(n, 4 + 1000 * rank)
+        counts_in = synth.make_counts(n, s, 40 + 1000 * rank)
+        self.gen_s = time.time() - t
+        row_of, self.row_ptr, self.col = ctx.cluster(*self.junc)
+        self.counts = np.zeros_like(counts_in)
+        self.counts[row_of] = counts_in
+        self.d_counts = ctx.to_device(self.counts)
+        self.d_row_ptr, self.d_col = ctx.to_device(self.row_ptr), ctx.to_device(self.col)
+        self.d_excl = ctx.empty((n, s), np.int64)
+        self.pairs = s * (s - 1) // 2
+        self.d_p = ctx.empty((n, self.pairs), np.float64)
+        self.units = n * self.pairs
+        self.alg_bytes = 8.0 * n * self.pairs + 12.0 * n * s     # 8 B per p-value + inputs once
+
+    def step(self):
+        self.ctx.ps_dev(self.d_counts, self.d_row_ptr, self.d_col, self.d_excl, None)
+        self.ctx.fisher_pairs_dev(self.d_counts, self.d_excl, self.d_p)
+
+    def describe(self):
+        return {"workload": f"pairwise {self.n} junctions x {self.s} samples per GPU = {self.pairs} pairs/junction "
+                            f"(BASELINE config 4 is 200k junctions over 8 GPUs)", "junctions_per_gpu": self.n,
+                "samples": self.s}
+
+    def verify(self):
+        from oracle import oracle_np as O
+        m = 2
+        cols = 12
+        excl = self.d_excl.to_host()[:m, :cols]
+        want = O.fisher_pairs(self.counts[:m, :cols], excl)
+        p = self.d_p.to_host()[:m]
+        idx = [i * self.s - i * (i + 1) // 2 + (j - i - 1) for i in range(cols - 1) for j in range(i + 1, cols)]
+        ok = np.allclose(p[:, idx], want, rtol=1e-9, atol=0)
+        _, want_excl = O.calculate_psi_vectorised(self.counts, self.row_ptr, self.col)
+        ok = ok and np.array_equal(self.d_excl.to_host(), want_excl)
+        return bool(ok), m * len(idx)
+
+    def cpu_baseline(self, sample):
+        from oracle import oracle_np as O
+        m = sample or 3
+        cols = 40
+        excl = self.d_excl.to_host()[:m, :cols]
+        t = time.time()
+        O.fisher_pairs(self.counts[:m, :cols], excl)
+        dt = time.time() - t
+        nt = m * cols * (cols - 1) // 2
+        return {"value": nt / dt, "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": f"{nt} tables ({m} junctions x {cols} samples): scipy.stats.fisher_exact per pair as "
+                          f"pairwise_fisher.py:164-179, {dt:.1f} s"}
+
+
+WORKLOADS = {"quant": QuantWorkload, "compare": CompareWorkload, "pairwise": PairwiseWorkload}
+
+
+def traffic_from_profiles(workload, n, s):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            for rec in json.load(fh):
+                if rec["workload"] == workload and rec["n"] == n and rec["s"] == s:
+                    return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def main():
+    args = parse_args()
+    dist = Dist(args.gpus)
+    ctx = Context(dist.local_rank if args.gpus > 1 else 0)
+    wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
+
+    for _ in range(args.warmup):
+        wl.step()
+    ctx.sync()
+    ctx.prof_enable(2)
+    ctx.prof_reset()
+    dist.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    ctx.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.prof_query(wl.kernel)
+    ctx.prof_enable(0)
+    elapsed = dist.max(elapsed)
+
+    verify = None
+    if not args.no_verify:
+        ok, checked = wl.verify()
+        verify = {"ok": ok, "checked": checked}
+
+    allgather = None
+    if args.gpus > 1:
+        # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction)
+        try:
+            uid = ctx.comm_unique_id() if dist.rank == 0 else None
+            uid = dist.bcast_bytes(uid, 128)
+            ctx.comm_init(uid, dist.rank, args.gpus)
+            send = ctx.to_device(np.full(wl.n, float(dist.rank)))
+            recv = ctx.empty(wl.n * args.gpus, np.float64)
+            ctx.allgather_dev(send, recv)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(5):
+                ctx.allgather_dev(send, recv)
+            ms = ctx.timer_stop() / 5
+            got = recv.to_host().reshape(args.gpus, wl.n)[:, 0]
+            allgather = {"ok": bool(np.array_equal(got, np.arange(args.gpus))), "bytes_per_rank": wl.n * 8,
+                         "ms": round(ms, 4)}
+        except Exception as e:  # reported, never hidden: the timed steps above contain no collective
+            allgather = {"ok": False, "error": str(e)[:300]}
+        dist.barrier()
+
+    cpu = None
+    if dist.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = wl.cpu_baseline(args.cpu_sample)
+
+    if dist.rank == 0:
+        total_units = wl.units * args.gpus * args.steps
+        avg_ms = kernel_ms / launches if launches else float("nan")
+        achieved = wl.alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
+        info = ctx.device_info()
+        line = {
+            "metric": wl.metric, "value": total_units / elapsed, "unit": wl.unit, "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
+            "data": "synthetic (seeded numpy PCG64; SURVEY.md 8(d))",
+            "config": dict(wl.describe(), parallelism=f"junction shards x{args.gpus}, one rank per GPU"),
+            "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "avg_kernel_ms": avg_ms,
+                         "launches": launches, "algorithmic_bytes_per_launch": wl.alg_bytes,
+                         "traffic": traffic_from_profiles(args.workload, wl.n, wl.s)},
+            "cpu_baseline": cpu, "verify": verify, "allgather": allgather,
+            "device": info["name"].strip(), "gen_seconds": round(wl.gen_s, 1),
+        }
+        print(json.dumps(line), flush=True)
+    dist.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,7 +79,7 @@ int sdice_cluster(sdice_ctx* ctx, int64_t n, const int32_t* chrom_rank, const in
 int sdice_cluster_col(sdice_ctx* ctx, int32_t* col, int64_t capacity);
 int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom_rank,
                       const int32_t* d_left, const int32_t* d_right, const int8_t* d_strand,
-                      int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz /* host out, or NULL to stay asynchronous */);
+                      int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz /* host out, may be NULL; the call synchronises to size col */);
 int sdice_cluster_col_dev(sdice_ctx* ctx, const int32_t** d_col, int64_t* nnz);
 
 /* ---- PS: replaces SPLICEDICE.calculatePsi (SPLICEDICE.py:297-310), counts_to_ps
@@ -154,6 +154,8 @@ int sdice_comm_destroy(sdice_ctx* ctx);
 int sdice_allgather_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
 
 /* ---- per-kernel timing with HIP events on the context's stream ---------------------- */
+/* on: 0 = off, 1 = every kernel, 2 = only the dominant kernel of each path (ps_tile_kernel,
+ * ranksum_*_kernel, fisher_pairs_kernel, rccl_allgather) so that a timed loop is not perturbed */
 int sdice_prof_enable(sdice_ctx* ctx, int on);
 int sdice_prof_reset(sdice_ctx* ctx);
 /* total device time and launch count of kernel `name` since the last reset (syncs) */

@@ -1,0 +1,155 @@
+"""`splicedice compare_sample_sets`: two-group rank-sum test per junction of an `_allPS.tsv`.
+
+Drop-in for splicedice/compareSampleSets.py (add_parser :124-159, run_with :163-270): same
+flags, same `<3 samples` exit, same output columns
+`event mean1 mean2 median1 median2 delta p-value corrected` (+ gene/overlapping/transcript_id
+with -a GTF), values printed as numpy float32 / float64 scalars.
+
+On the GPU: the per-row loop :216-232 (NaN drop, <3 skip, scipy ranksums, medians, means)
+-> sdice_ranksum; multipletests(..., "fdr_bh") :235 -> sdice_bh over the tested rows.
+The GTF annotation columns are host string work, as in the reference.
+"""
+import sys
+
+import numpy as np
+
+from .engine import Context
+
+
+def samples_from_manifest(path):
+    """First whitespace-separated token of every line (compareSampleSets.py:105-115)."""
+    with open(path) as fin:
+        return [line.split()[0] for line in fin]
+
+
+def column_indices(group, cols):
+    """Columns of the table that belong to the group, in TABLE order (compareSampleSets.py:96-102)."""
+    return np.nonzero(np.isin(cols, group))[0].astype(np.int32)
+
+
+def read_ps_table(path):
+    """`_allPS.tsv` -> (row names array, column names array, float32 matrix), :193-204."""
+    rows, data = [], []
+    with open(path) as tsv:
+        headers = tsv.readline().strip().split("\t")[1:]
+        for line in tsv:
+            row = line.strip().split("\t")
+            rows.append(row[0])
+            data.append(row[1:])
+    matrix = np.array(data, dtype="float32")
+    if matrix.ndim != 2:
+        matrix = matrix.reshape(len(rows), len(headers))
+    return np.array(rows), np.array(headers), matrix
+
+
+def read_annotation(gtf_path):
+    """GTF -> (junction -> gene names, (chrom,strand) -> {(start,stop): gene names},
+    junction -> transcript ids); restates getAnnotated (compareSampleSets.py:32-93)."""
+    def attr(info, key):
+        return [x[1] for x in info if key in x[0]][0]
+
+    gene_coords, genes, transcripts = {}, {}, {}
+    with open(gtf_path) as gtf:
+        for line in gtf:
+            if line.startswith("#"):
+                continue
+            row = line.rstrip().split("\t")
+            info = [x.split('"') for x in row[8].split(";")]
+            chrom, strand = row[0], row[6]
+            start, stop = int(row[3]), int(row[4]) - 1
+            if row[2] == "transcript":
+                tid = attr(info, "transcript_id")
+                genes[tid] = attr(info, "gene_name")
+                transcripts[(tid, chrom, strand)] = []
+            elif row[2] == "exon":
+                transcripts[(attr(info, "transcript_id"), chrom, strand)].append((start, stop))
+            elif row[2] == "gene":
+                gene_name = attr(info, "gene_name")
+                attr(info, "gene_id")      # the reference requires the attribute to exist
+                gene_coords.setdefault((chrom, strand), {}).setdefault((start, stop), []).append(gene_name)
+    annotated, transcript_ids = {}, {}
+    for (tid, chromosome, strand), exons in transcripts.items():
+        for i in range(len(exons) - 1):
+            junction = (chromosome, exons[i][1], exons[i + 1][0], strand)
+            if junction in annotated:
+                if genes[tid] not in annotated[junction]:
+                    annotated[junction].append(genes[tid])
+                    transcript_ids[junction].append(tid)
+            else:
+                annotated[junction] = [genes[tid]]
+                transcript_ids[junction] = [tid]
+    return annotated, gene_coords, transcript_ids
+
+
+def compare(matrix, g1_idx, g2_idx, ctx):
+    """-> (kept row indices, dict of compacted per-row results incl. BH-corrected p)."""
+    res = ctx.ranksum(matrix, g1_idx, g2_idx)
+    keep = np.flatnonzero(res["tested"])
+    out = {k: res[k][keep] for k in ("p", "med1", "med2", "mean1", "mean2", "delta")}
+    out["corrected"] = ctx.bh(out["p"]) if keep.size else np.zeros(0)
+    return keep, out
+
+
+def add_parser(parser):
+    parser.add_argument("--psiSPLICEDICE", type=str, required=True,
+                        help="Compressed NPZ formatted PSI matrix from 'splicedice quant'.")
+    parser.add_argument("-m1", "--manifest1", type=str, required=True,
+                        help="Manifest containing samples for sample set group1")
+    parser.add_argument("-m2", "--manifest2", type=str, required=True,
+                        help="Manifest containing samples for sample set group2")
+    parser.add_argument("-a", "--annotation", type=str, required=False, default="",
+                        help="Optional GTF file to label known splice junctions and genes")
+    parser.add_argument("-o", "--outputFile", type=str, required=True,
+                        help="Output filename for tab-separated table")
+
+
+def run_with(args, ctx=None):
+    g1 = samples_from_manifest(args.manifest1)
+    g2 = samples_from_manifest(args.manifest2)
+    if len(g1) < 3 or len(g2) < 3:
+        print("Cannot conduct wilcoxon with less than 3 samples in either group. Exit.", file=sys.stderr)
+        sys.exit(1)
+
+    rows, cols, matrix = read_ps_table(args.psiSPLICEDICE)
+    g1_idx = column_indices(g1, cols)
+    g2_idx = column_indices(g2, cols)
+
+    own_ctx = ctx is None
+    ctx = ctx if ctx is not None else Context(0)
+    try:
+        keep, r = compare(matrix, g1_idx, g2_idx, ctx)
+    finally:
+        if own_ctx:
+            ctx.close()
+
+    base_header = "event\tmean1\tmean2\tmedian1\tmedian2\tdelta\tp-value\tcorrected"
+    with open(args.outputFile, "w") as tsv:
+        if args.annotation:
+            print(base_header + "\tgene\toverlapping\ttranscript_id", file=tsv)
+            annotated, gene_coords, transcript_ids = read_annotation(args.annotation)
+        else:
+            print(base_header, file=tsv)
+        for n, ri in enumerate(keep):
+            name = rows[ri]
+            fields = [name, r["mean1"][n], r["mean2"][n], r["med1"][n], r["med2"][n], r["delta"][n], r["p"][n],
+                      r["corrected"][n]]
+            if args.annotation:
+                chromosome, coords, strand = name.split(":")
+                start, stop = (int(x) for x in coords.split("-"))
+                start -= 1
+                stop += 1
+                junction = (chromosome, start, stop, strand)
+                overlaps = []
+                for (gene_start, gene_stop), gene_names in gene_coords.get((chromosome, strand), {}).items():
+                    if gene_start <= start <= gene_stop or gene_start <= stop <= gene_stop:
+                        overlaps.extend(gene_names)
+                fields += [",".join(annotated.get(junction, ["nan"])), ",".join(overlaps),
+                           ",".join(transcript_ids.get(junction, ["nan"]))]
+            print(*fields, sep="\t", file=tsv)
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser()
+    add_parser(p)
+    run_with(p.parse_args())

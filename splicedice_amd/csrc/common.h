@@ -75,6 +75,7 @@ struct sdice_ctx {
 
     // profiling
     bool prof_on = false;
+    int prof_mode = 0;   // 1 = every kernel, 2 = only the dominant kernel of each path
     std::vector<std::string> prof_names;
     std::map<std::string, int> prof_ids;
     std::vector<ProfStat> prof_stats;

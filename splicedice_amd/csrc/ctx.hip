@@ -193,6 +193,10 @@ static hipEvent_t pool_get(sdice_ctx* ctx) {
 
 int sd_prof_begin(sdice_ctx* ctx, const char* name) {
     if (!ctx->prof_on) return -1;
+    if (ctx->prof_mode == 2 && strcmp(name, "ps_tile_kernel") != 0 && strcmp(name, "ranksum_lane_kernel") != 0 &&
+        strcmp(name, "ranksum_block_kernel") != 0 && strcmp(name, "fisher_pairs_kernel") != 0 &&
+        strcmp(name, "rccl_allgather") != 0)
+        return -1;
     if (ctx->prof_pending.size() >= 8192 && sd_prof_drain(ctx) != SDICE_OK) return -1;
     int id;
     auto it = ctx->prof_ids.find(name);
@@ -239,6 +243,7 @@ extern "C" int sdice_prof_enable(sdice_ctx* ctx, int on) {
     SD_ARG(ctx, "ctx is NULL");
     if (!on) SD_TRY(sd_prof_drain(ctx));
     ctx->prof_on = on != 0;
+    ctx->prof_mode = on;
     return SDICE_OK;
 }
 

@@ -95,7 +95,8 @@ class Context:
         check(self.lib.sdice_sync(self.h), "sdice_sync")
 
     def prof_enable(self, on=True):
-        check(self.lib.sdice_prof_enable(self.h, 1 if on else 0), "sdice_prof_enable")
+        """on: False/0 off, True/1 every kernel, 2 dominant kernels only."""
+        check(self.lib.sdice_prof_enable(self.h, int(on)), "sdice_prof_enable")
 
     def prof_reset(self):
         check(self.lib.sdice_prof_reset(self.h), "sdice_prof_reset")

@@ -1,0 +1,129 @@
+"""`splicedice pairwise`: Fisher's exact test between every pair of samples, per junction.
+
+Drop-in for splicedice/pairwise_fisher.py (add_parser :71-111, run_with :114-200): same flags,
+same stdout lines, same output table `clusterID <a_b columns>` with str(float64) cells.
+
+On the GPU: the exclusion gather :158-160 (an O(N) name scan per event in the reference)
+-> sdice_ps (integer sums over a CSR built once on the host from the name lists); the per-pair
+scipy fisher_exact :164-179 -> sdice_fisher_pairs; Benjamini-Hochberg :182-193 -> sdice_bh /
+sdice_bh_columns.
+"""
+import numpy as np
+
+from . import textio
+from .engine import Context
+
+
+def get_clusters(filename):
+    """event -> list of overlap names; whitespace split, a lone name means no overlaps
+    (pairwise_fisher.py:26-43; its filter_list argument never changes the result)."""
+    clusters = {}
+    with open(filename) as fh:
+        for line in fh:
+            try:
+                event, mxes = line.rstrip().split()
+                mxes = mxes.split(",")
+            except ValueError:
+                event = line.strip()
+                mxes = []
+            clusters[event] = mxes
+    return clusters
+
+
+def get_event_counts(filename, filter_list=None):
+    """samples, events, int32 counts; `-f` keeps only listed rows (pairwise_fisher.py:46-61)."""
+    events, counts = [], []
+    with open(filename) as tsv:
+        samples = tsv.readline().rstrip().split("\t")[1:]
+        for line in tsv:
+            row = line.rstrip().split("\t")
+            if filter_list is None or row[0] in filter_list:
+                events.append(row[0])
+                counts.append(row[1:])
+    mat = np.array(counts, dtype=float).reshape(len(events), -1) if events else np.zeros((0, len(samples)))
+    return samples, events, textio.counts_to_int32(mat, filename)
+
+
+def exclusion_csr(events, clusters):
+    """CSR over table rows: for event n, every table row whose name is in clusters[event]
+    (np.isin(events, clusters[events[n]]), pairwise_fisher.py:158: each matching row once)."""
+    rows_of = {}
+    for r, name in enumerate(events):
+        rows_of.setdefault(name, []).append(r)
+    row_ptr = np.zeros(len(events) + 1, dtype=np.int64)
+    col = []
+    for n, name in enumerate(events):
+        for other in dict.fromkeys(clusters[name]):       # KeyError for an unknown event, as the reference
+            col.extend(rows_of.get(other, ()))
+        row_ptr[n + 1] = len(col)
+    return row_ptr, np.asarray(col, dtype=np.int32)
+
+
+def add_parser(parser):
+    parser.add_argument("--inclusionSPLICEDICE", type=str, required=True,
+                        help="Compressed NPZ formatted Inclusion count matrix from quantSPLICEDICE.")
+    parser.add_argument("-c", "--clusters", type=str, required=True, help="Clusters table.")
+    parser.add_argument("--chi2", action="store_true", default=False,
+                        help="Use X^2 instead of fishers. Quicker, not as sensitive.")
+    parser.add_argument("--multiple_test_correction", default="pairwise", choices=["pairwise", "all", "none"],
+                        help="Correction via Benjamini-Hochberg. Options are "
+                             "[pairwise (default): all p-values per sample pair; "
+                             "all: all p-values for every sample pair together;\n"
+                             "none: no multiple test correction]")
+    parser.add_argument("-f", "--filter_list",
+                        help="txt file where each line is a event to analyze, can speed up fisher test analysis")
+    parser.add_argument("-o", "--output", default="pairwise.tsv",
+                        help="tab-separated output filename (default uses input prefix)")
+
+
+def run_with(args, ctx=None):
+    if args.chi2:
+        # SURVEY.md 8(f) "next" row F7; refusing is louder than silently running Fisher
+        raise NotImplementedError("pairwise --chi2 is not built yet in the MI355X engine (Fisher exact only)")
+    if args.filter_list is not None:
+        with open(args.filter_list, "r") as fh:
+            filter_list = set(line.rstrip() for line in fh)
+    else:
+        filter_list = None
+
+    samples, events, counts = get_event_counts(args.inclusionSPLICEDICE, filter_list)
+    print("Counts loaded from", args.inclusionSPLICEDICE, "...")
+    clusters = get_clusters(args.clusters)
+    print("Clusters loaded from", args.clusters, "...")
+    pairs = [(i, j) for i in range(len(samples) - 1) for j in range(i + 1, len(samples))]
+    columns = [f"{samples[a]}_{samples[b]}" for a, b in pairs]
+    print("Analyzing pairs:")
+    print(",".join(columns))
+
+    totaln = len(events)
+    for n in range(0, totaln, 50):
+        print(f"[{n} / {totaln}] events analyzed...")
+
+    own_ctx = ctx is None
+    ctx = ctx if ctx is not None else Context(0)
+    try:
+        row_ptr, col = exclusion_csr(events, clusters)
+        if totaln and pairs:
+            excl = ctx.ps(counts, row_ptr, col, want_excl=True, want_ps=False)
+            parray = ctx.fisher_pairs(counts, excl)
+            if args.multiple_test_correction == "all":
+                parray = ctx.bh(parray.ravel()).reshape(parray.shape)
+            elif args.multiple_test_correction == "pairwise":
+                parray = ctx.bh_columns(parray)
+        else:
+            parray = np.zeros((totaln, len(pairs)))
+    finally:
+        if own_ctx:
+            ctx.close()
+
+    with open(args.output, "w") as outfile:
+        outfile.write("clusterID\t" + "\t".join(columns) + "\n")
+        for name, pvalues in zip(events, parray):
+            outfile.write(name + "\t" + "\t".join(str(p) for p in pvalues) + "\n")
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser()
+    add_parser(p)
+    run_with(p.parse_args())

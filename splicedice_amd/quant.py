@@ -1,0 +1,300 @@
+"""`splicedice quant`: manifest of junction files -> clusters, inclusion counts, PS table.
+
+Drop-in for the reference sub-command (splicedice/SPLICEDICE.py: add_parser :377-402,
+run_with :404-409): same flags, same stdout banners, byte-identical output files
+`<prefix>_junctions.bed`, `_allClusters.tsv`, `_inclusionCounts.tsv`, `_allPS.tsv`
+(+ `_drimTable.tsv` with --drim).
+
+What moved to the GPU (through the C ABI, include/sdice.h):
+  getClusters + junctionIndex sort (SPLICEDICE.py:230-255, :96)  -> sdice_cluster
+  calculatePsi (SPLICEDICE.py:297-310)                           -> sdice_ps (+ sdice_mark_low)
+Text parsing and formatting stay on the host, as in the reference.
+"""
+from time import time
+
+import numpy as np
+
+from . import textio
+from .engine import Context
+
+STRAND_SYMBOL = {"0": "0", "1": "+", "2": "-", "+": "+", "-": "-"}   # SPLICEDICE.py:150
+VALID_MOTIFS = {"gtag_only": {1, 2}, "gc_at": {1, 2, 3, 4, 5}, "all": {0, 1, 2, 3, 4, 5, 6}}   # :153
+BED_LIKE = ("bed", "splicedicebed", "leafcutter")
+
+
+class Sample:
+    """One manifest row (SPLICEDICE.py:11-46): name, path, sniffed file type, metadata, condition."""
+
+    def __init__(self, row):
+        self.name = row[0]
+        self.filename = row[1]
+        upper = self.filename.upper()
+        if upper.endswith(".BED"):
+            self.type = "bed"
+            with open(self.filename) as bedfile:
+                info = bedfile.readline().split("\t")[3].split(";")
+                if info[0].startswith("e:") and info[1].startswith("o:"):
+                    self.type = "splicedicebed"
+        elif upper.endswith("SJ.OUT.TAB"):
+            self.type = "SJ"
+        elif upper.endswith(".BAM"):
+            self.type = "bam"
+        elif upper.endswith("LEAFCUTTER.JUNC"):
+            self.type = "leafcutter"
+        else:
+            self.type = "unknown"
+        self.metadata = row[2]
+        self.condition = row[3]
+
+
+class Timer:
+    """Stage stopwatch printing [h:mm:ss.ss] like SPLICEDICE.py:48-66."""
+
+    def __init__(self):
+        self.start = time()
+        self.checkpoint = self.start
+
+    @staticmethod
+    def _fmt(passed):
+        hours = int(passed // 3600)
+        minutes = int((passed % 3600) // 60)
+        seconds = passed % 60
+        return f"[{hours}:{minutes:02d}:{seconds:02.2f}]"
+
+    def total(self):
+        return self._fmt(time() - self.start)
+
+    def check(self):
+        now = time()
+        passed = now - self.checkpoint
+        self.checkpoint = now
+        return self._fmt(passed)
+
+
+def parse_manifest(path):
+    manifest = []
+    with open(path, "r") as fh:
+        for line in fh:
+            manifest.append(Sample(line.rstrip().split("\t")))
+    return manifest
+
+
+def _sj_score(row, no_multimap):
+    return int(row[6]) if no_multimap else int(row[6]) + int(row[7])
+
+
+def get_all_junctions(manifest, args):
+    """Union of junctions passing the per-type filters (SPLICEDICE.py:147-228)."""
+    valid_motifs = VALID_MOTIFS[args.filter]
+    junctions = set()
+    for sample in manifest:
+        with open(sample.filename, "r") as fh:
+            if sample.type == "SJ":
+                for line in fh:
+                    row = line.rstrip().split("\t")
+                    left, right = int(row[1]) - 1, int(row[2])
+                    strand = STRAND_SYMBOL[row[3]]
+                    length = right - left
+                    if (args.minLength < length < args.maxLength and strand != "0"
+                            and _sj_score(row, args.noMultimap) >= args.minUnique
+                            and int(row[4]) in valid_motifs):
+                        junctions.add((row[0], left, right, strand))
+            elif sample.type == "splicedicebed":
+                for line in fh:
+                    row = line.rstrip().split("\t")
+                    score = int(row[4])
+                    info = [x.split(":") for x in row[3].split(";")]
+                    left, right = int(row[1]), int(row[2])
+                    length = right - left
+                    if info[3][1] == "?":      # un-annotated junctions must earn their place (:194-203)
+                        if score < args.minUnique:
+                            continue
+                        if length > args.maxLength or length < args.minLength:
+                            continue
+                        if int(info[1][1]) < args.minOverhang:
+                            continue
+                        if float(info[0][1]) < args.minEntropy or float(info[0][2]) < args.minEntropy:
+                            continue
+                    if row[5] in ("+", "-"):
+                        junctions.add((row[0], left, right, row[5]))
+            elif sample.type in ("bed", "leafcutter"):
+                for line in fh:
+                    row = line.rstrip().split("\t")
+                    if int(row[4]) < args.minUnique:
+                        continue
+                    left, right = int(row[1]), int(row[2])
+                    length = right - left
+                    if length > args.maxLength or length < args.minLength:
+                        continue
+                    if row[5] in ("+", "-"):
+                        junctions.add((row[0], left, right, row[5]))
+    return junctions
+
+
+def get_junction_counts(manifest, index, args):
+    """counts int32 [N, S] + `low` flat indices (SPLICEDICE.py:257-295).  No score filter
+    here; a later line for the same junction overwrites an earlier one."""
+    n, s = len(index), len(manifest)
+    counts = np.zeros((n, s), dtype=np.int64)
+    low = []
+    for si, sample in enumerate(manifest):
+        with open(sample.filename, "r") as fh:
+            if sample.type in BED_LIKE:
+                for line in fh:
+                    row = line.rstrip().split("\t")
+                    r = index.get((row[0], int(row[1]), int(row[2]), row[5]))
+                    if r is not None:
+                        score = int(row[4])
+                        counts[r, si] = score
+                        if args.lowCoverageNan and score < args.minUnique:
+                            low.append(r * s + si)
+            elif sample.type == "SJ":
+                for line in fh:
+                    row = line.rstrip().split("\t")
+                    r = index.get((row[0], int(row[1]) - 1, int(row[2]), {"0": "0", "1": "+", "2": "-"}[row[3]]))
+                    if r is not None:
+                        counts[r, si] = _sj_score(row, args.noMultimap)
+    if counts.size and (counts.min() < 0 or counts.max() >= 2 ** 31):
+        raise ValueError("junction counts must be non-negative and below 2**31")
+    return counts.astype(np.int32), np.asarray(low, dtype=np.int64)
+
+
+class Quant:
+    """The quant pipeline; attribute names follow the reference class (SPLICEDICE.py:71-131)."""
+
+    def __init__(self, manifest_filename, output_prefix, args, ctx=None):
+        self.args = args
+        self.manifestFilename = manifest_filename
+        self.outputPrefix = output_prefix
+        own_ctx = ctx is None
+        self.ctx = ctx if ctx is not None else Context(0)
+        try:
+            self._run()
+        finally:
+            if own_ctx:
+                self.ctx.close()
+
+    def _run(self):
+        timer = Timer()
+        print("Parsing manifest...")
+        self.manifest = parse_manifest(self.manifestFilename)
+        print("\tDone", timer.check())
+
+        print(f"Getting all junctions from {len(self.manifest)} files...")
+        junction_set = get_all_junctions(self.manifest, self.args)
+        print("\tDone", timer.check())
+
+        print(f"Finding clusters from {len(junction_set)} junctions...")
+        junction_list = list(junction_set)
+        _, cr, left, right, strand = textio.junction_arrays(junction_list)
+        row_of, self.row_ptr, self.col = self.ctx.cluster(cr, left, right, strand)
+        self.junctions = [None] * len(junction_list)          # row order (SPLICEDICE.py:96)
+        for i, r in enumerate(row_of):
+            self.junctions[r] = junction_list[i]
+        self.junctionIndex = {j: r for r, j in enumerate(self.junctions)}
+        self.names = [textio.junction_name(j) for j in self.junctions]
+        print("\tDone", timer.check())
+
+        print("Writing cluster file...")
+        self.write_clusters()
+        print("\tDone", timer.check())
+
+        print("Writing junction bed file...")
+        self.write_junction_bed()
+        print("\tDone", timer.check())
+
+        print("Gathering junction counts...")
+        self.counts, self.low = get_junction_counts(self.manifest, self.junctionIndex, self.args)
+        print("\tDone", timer.check())
+
+        print("Writing inclusion counts...")
+        self.write_inclusions()
+        print("\tDone", timer.check())
+
+        print("Calculating PS values...")
+        self.psi = self.ctx.ps(self.counts, self.row_ptr, self.col)
+        if self.args.lowCoverageNan and self.low.size:
+            self.psi = self.ctx.mark_low(self.psi, self.low)
+        print("\tDone", timer.check())
+
+        print("Writing PS values...")
+        self.write_all_psi()
+        print("\tDone", timer.check())
+
+        if self.args.drim:
+            print("Writing drim table...")
+            self.write_drim_table()
+            print("\tDone", timer.check())
+
+        print("All done", timer.total())
+
+    # ------------------------------------------------------------------ writers (SPLICEDICE.py:316-370)
+    def write_junction_bed(self):
+        with open(f"{self.outputPrefix}_junctions.bed", "w") as out:
+            for j, name in zip(self.junctions, self.names):
+                out.write(f"{j[0]}\t{j[1]}\t{j[2]}\t{name}\t0\t{j[3]}\n")
+
+    def write_clusters(self):
+        names, rp, col = self.names, self.row_ptr, self.col
+        with open(f"{self.outputPrefix}_allClusters.tsv", "w") as out:
+            for r, name in enumerate(names):
+                out.write(name + "\t" + ",".join(names[c] for c in col[rp[r]:rp[r + 1]]) + "\n")
+
+    def _sample_header(self, first):
+        return first + "\t" + "\t".join(s.name for s in self.manifest) + "\n"
+
+    def write_inclusions(self):
+        with open(f"{self.outputPrefix}_inclusionCounts.tsv", "w") as out:
+            out.write(self._sample_header("cluster"))
+            for name, row in zip(self.names, self.counts):
+                out.write(name + "\t" + "\t".join(f"{x:.0f}" for x in row.astype(np.float32)) + "\n")
+
+    def write_all_psi(self):
+        with open(f"{self.outputPrefix}_allPS.tsv", "w") as out:
+            out.write(self._sample_header("cluster"))
+            for name, row in zip(self.names, self.psi):
+                out.write(name + "\t" + "\t".join(f"{x:.3f}" for x in row) + "\n")
+
+    def write_drim_table(self):
+        counts_str = self.counts.astype(np.float32).astype("str")
+        with open(f"{self.outputPrefix}_drimTable.tsv", "w") as out:
+            out.write("gene\tfeature_id\t" + "\t".join(s.name for s in self.manifest) + "\n")
+            rp, col = self.row_ptr, self.col
+            for r, name in enumerate(self.names):
+                for other in [r] + list(col[rp[r]:rp[r + 1]]):
+                    print(f"cl_{r}_{name}", f"{self.names[other]}_{r}", "\t".join(counts_str[other]), sep="\t", file=out)
+
+
+def add_parser(parser):
+    """Flag surface of SPLICEDICE.py:377-402."""
+    parser.add_argument("--manifest", "-m", action="store", required=True,
+                        help="tab-separated list of samples with file paths")
+    parser.add_argument("--output_prefix", "-o", action="store", required=True,
+                        help="prefix for output filenames")
+    parser.add_argument("--maxLength", type=int, default=50000, help="maximum splice junction size")
+    parser.add_argument("--minLength", type=int, default=50, help="minimum splice junction size")
+    parser.add_argument("--minOverhang", type=int, default=5,
+                        help="minimum overlap on reads to support splice junction")
+    parser.add_argument("--drim", action="store_true", help="create table for use by DRIMSeq")
+    parser.add_argument("--noMultimap", action="store_true",
+                        help="use only reads that uniquely map to one location")
+    parser.add_argument("--filter", default="gtag_only", choices=["gtag_only"],
+                        help="donor and acceptor intron sequences to include.")
+    parser.add_argument("--minUnique", type=int, default=5,
+                        help="minimum number of unique reads to support splice junction")
+    parser.add_argument("--lowCoverageNan", action="store_true",
+                        help="Report NaN for splicing events with coverage below minUnique")
+    parser.add_argument("--minEntropy", type=float, default=1,
+                        help="Shannon's diversity index associated with a junction, minumum required for "
+                             "inclusion [Default 1]")
+
+
+def run_with(args):
+    Quant(args.manifest, args.output_prefix, args)
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser(description="Percent-Spliced quantification (MI355X engine).")
+    add_parser(p)
+    run_with(p.parse_args())

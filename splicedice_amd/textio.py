@@ -1,0 +1,66 @@
+"""Host-side text I/O shared by the sub-commands: junction names, manifests, count/PS tables.
+
+The file formats are the reference's inter-stage contract; nothing
+here is on the device path.
+"""
+import numpy as np
+
+STRAND_CODE = {"+": 0, "-": 1}
+STRAND_SYM = ("+", "-")
+
+
+def junction_name(j):
+    """(chrom, left, right, strand) -> 'chrom:left-right:strand' (SPLICEDICE.py:312-314)."""
+    return f"{j[0]}:{j[1]}-{j[2]}:{j[3]}"
+
+
+def parse_junction_name(name):
+    """Inverse of junction_name (counts_to_ps.py:53-56).  Chromosome names without ':' only,
+    as in the reference (a 3-way split)."""
+    chromosome, coords, strand = name.split(":")
+    start, end = (int(x) for x in coords.split("-"))
+    return (chromosome, start, end, strand)
+
+
+def junction_arrays(junctions):
+    """list of tuples -> (chrom_names_sorted, chrom_rank int32, left int32, right int32, strand int8).
+
+    chrom_rank is the rank of the chromosome name under Python string sort, strand 0 = '+',
+    1 = '-', which makes integer order on the device equal to the reference's tuple order
+    (SPLICEDICE.py:96,237: chr1 < chr10 < chr2, '+' < '-').
+    """
+    names = sorted({j[0] for j in junctions})
+    rank = {c: i for i, c in enumerate(names)}
+    n = len(junctions)
+    cr = np.fromiter((rank[j[0]] for j in junctions), dtype=np.int32, count=n)
+    left = np.fromiter((j[1] for j in junctions), dtype=np.int64, count=n)
+    right = np.fromiter((j[2] for j in junctions), dtype=np.int64, count=n)
+    bad = [j for j in junctions if j[3] not in STRAND_CODE]
+    if bad:
+        raise ValueError(f"junction strand must be '+' or '-': {bad[0]!r}")
+    if n and (left.min() < 0 or right.max() >= 2 ** 31 or (right < left).any()):
+        raise ValueError("junction coordinates must satisfy 0 <= left <= right < 2**31")
+    strand = np.fromiter((STRAND_CODE[j[3]] for j in junctions), dtype=np.int8, count=n)
+    return names, cr, left.astype(np.int32), right.astype(np.int32), strand
+
+
+def counts_to_int32(values, what):
+    """float table cells -> int32; the engine sums integers (the reference's float sums of
+    integer-valued counts are the same numbers)."""
+    arr = np.asarray(values, dtype=np.float64)
+    if arr.size and (not np.isfinite(arr).all() or (arr < 0).any() or (arr >= 2 ** 31).any()
+                     or (arr != np.floor(arr)).any()):
+        raise ValueError(f"{what}: counts must be non-negative integers below 2**31")
+    return arr.astype(np.int32)
+
+
+def read_table(path, strip_lines=False):
+    """'cluster<TAB>s0<TAB>s1...' table -> (header_line, names list, rows list of str lists)."""
+    names, rows = [], []
+    with open(path) as fh:
+        header = fh.readline()
+        for line in fh:
+            row = (line.strip() if strip_lines else line.rstrip()).split("\t")
+            names.append(row[0])
+            rows.append(row[1:])
+    return header, names, rows
