@@ -8,59 +8,165 @@
 // (chrom, left, right, strand) (:96).  Per junction the neighbour list order is: earlier
 // junctions of the sweep, most recent first, then later ones in sweep order.
 //
-// Device formulation (no sweep): in sweep order p, with composite keys
-//   ckL[p] = seg<<32 | left,  ckR[p] = seg<<32 | right,   seg = chrom<<1 | strand
-//   * later neighbours of p are the contiguous range (p, ub_p),
-//       ub_p = upper_bound(ckL, seg_p<<32 | right_p)           (galloping binary search)
-//   * earlier neighbours are the q < p with ckR[q] >= seg_p<<32 | left_p; the backward walk
-//     stops at the first q whose running prefix maximum of ckR drops below the target and
-//     skips 64-aligned blocks whose block maximum is below it.
-//   degree -> exclusive scan (row order) -> fill.
+// Device formulation (no sweep):
+//   1. ONE radix sort into sweep order on a packed key
+//        chrom | strand | left - min_left | right - left        (field widths from a reduction)
+//      (falls back to two sorts on wider keys when the fields do not fit 64 bits).
+//   2. Everything else is decoded from the sorted keys, no gathers: composite keys
+//        ckL[p] = seg<<32 | left,  ckR[p] = seg<<32 | right,   seg = chrom<<1 | strand.
+//   3. The output row of sweep position p: both strands of a chromosome occupy the same index
+//      range in row order and in sweep order, and within one strand the two orders agree, so
+//        row(p) = chrom_start + (p - own_strand_start) + #{other strand: (left,right) < or <= mine}
+//      -- one binary search in the other strand's sorted segment.
+//   4. Later neighbours of p are the contiguous range (p, ub_p),
+//        ub_p = upper_bound(ckL, seg_p<<32 | right_p)           (galloping binary search);
+//      earlier neighbours are the q < p with ckR[q] >= seg_p<<32 | left_p; the backward walk
+//      stops at the first q whose running prefix maximum of ckR drops below the target and
+//      skips 64-aligned blocks whose block maximum is below it.
+//   5. degree -> exclusive scan (row order) -> fill.
 #include "common.h"
 
 int sd_inclusive_max_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, uint64_t* d_out);
 
 namespace {
 
-// red[0]=OR(keyQ) red[1]=AND(keyQ) red[2]=OR(chrom) red[3]=AND(chrom) red[4]=error flag
-__global__ void __launch_bounds__(256) build_keys_kernel(const int32_t* __restrict__ chrom,
-                                                         const int32_t* __restrict__ left,
-                                                         const int32_t* __restrict__ right,
-                                                         const int8_t* __restrict__ strand, int64_t n,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                                                         unsigned long long* __restrict__ red) {
-    __shared__ unsigned long long sh[5][4];
-    unsigned long long o1 = 0, a1 = ~0ull, o2 = 0, a2 = ~0ull, err = 0;
+// red[0..1] OR/AND of (left<<32 | right<<1 | strand); red[2..3] OR/AND of chrom; red[4] error flag;
+// red[5] max row reach (filled later); red[6] min left; red[7] max left; red[8] max (right-left)
+constexpr int RED_WORDS = 12;
+
+__global__ void __launch_bounds__(256) reduce_fields_kernel(const int32_t* __restrict__ chrom,
+                                                            const int32_t* __restrict__ left,
+                                                            const int32_t* __restrict__ right,
+                                                            const int8_t* __restrict__ strand, int64_t n,
+                                                            unsigned long long* __restrict__ red) {
+    __shared__ unsigned long long sh[RED_WORDS][4];
+    unsigned long long o1 = 0, a1 = ~0ull, o2 = 0, a2 = ~0ull, err = 0, mnl = ~0ull, mxl = 0, mxn = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int32_t l = left[i], r = right[i], c = chrom[i];
         const int st = strand[i];
-        if (l < 0 || r < l || c < 0 || (st != 0 && st != 1)) err = 1;
+        if (l < 0 || r < l || c < 0 || (st != 0 && st != 1)) { err = 1; continue; }
         const uint64_t k = ((uint64_t)(uint32_t)l << 32) | ((uint64_t)(uint32_t)r << 1) | (uint64_t)(st & 1);
-        keys[i] = k;
-        idx[i] = (uint32_t)i;
         o1 |= k; a1 &= k;
         o2 |= (uint64_t)(uint32_t)c; a2 &= (uint64_t)(uint32_t)c;
+        mnl = min(mnl, (unsigned long long)l); mxl = max(mxl, (unsigned long long)l);
+        mxn = max(mxn, (unsigned long long)(r - l));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         o1 |= __shfl_xor(o1, o); a1 &= __shfl_xor(a1, o);
         o2 |= __shfl_xor(o2, o); a2 &= __shfl_xor(a2, o);
         err |= __shfl_xor(err, o);
+        mnl = min(mnl, (unsigned long long)__shfl_xor(mnl, o));
+        mxl = max(mxl, (unsigned long long)__shfl_xor(mxl, o));
+        mxn = max(mxn, (unsigned long long)__shfl_xor(mxn, o));
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[0][w] = o1; sh[1][w] = a1; sh[2][w] = o2; sh[3][w] = a2; sh[4][w] = err; }
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][w] = o1; sh[1][w] = a1; sh[2][w] = o2; sh[3][w] = a2; sh[4][w] = err;
+        sh[6][w] = mnl; sh[7][w] = mxl; sh[8][w] = mxn;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; ++k) {
             sh[0][0] |= sh[0][k]; sh[1][0] &= sh[1][k]; sh[2][0] |= sh[2][k]; sh[3][0] &= sh[3][k]; sh[4][0] |= sh[4][k];
+            sh[6][0] = min(sh[6][0], sh[6][k]); sh[7][0] = max(sh[7][0], sh[7][k]); sh[8][0] = max(sh[8][0], sh[8][k]);
         }
-        atomicOr(&red[0], sh[0][0]);
-        atomicAnd(&red[1], sh[1][0]);
-        atomicOr(&red[2], sh[2][0]);
-        atomicAnd(&red[3], sh[3][0]);
+        atomicOr(&red[0], sh[0][0]); atomicAnd(&red[1], sh[1][0]);
+        atomicOr(&red[2], sh[2][0]); atomicAnd(&red[3], sh[3][0]);
         if (sh[4][0]) atomicOr(&red[4], 1ull);
+        atomicMin(&red[6], sh[6][0]); atomicMax(&red[7], sh[7][0]); atomicMax(&red[8], sh[8][0]);
     }
+}
+
+// ------------------------------------------------------------------ packed (single sort) path
+struct Pack {
+    int bN;            // bits of (right - left)
+    int bL;            // bits of (left - min_left)
+    uint32_t min_left;
+    __host__ __device__ int seg_shift() const { return bN + bL; }
+};
+
+__global__ void __launch_bounds__(256) pack_keys_kernel(const int32_t* __restrict__ chrom,
+                                                        const int32_t* __restrict__ left,
+                                                        const int32_t* __restrict__ right,
+                                                        const int8_t* __restrict__ strand, int64_t n, Pack pk,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t seg = ((uint64_t)(uint32_t)chrom[i] << 1) | (uint64_t)(strand[i] & 1);
+    const uint64_t l = (uint32_t)left[i] - pk.min_left;
+    const uint64_t len = (uint32_t)(right[i] - left[i]);
+    keys[i] = (seg << pk.seg_shift()) | (l << pk.bN) | len;
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) decode_keys_kernel(const uint64_t* __restrict__ keys, int64_t n, Pack pk,
+                                                          uint64_t* __restrict__ ckL, uint64_t* __restrict__ ckR) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t k = keys[p];
+    const uint64_t seg = k >> pk.seg_shift();
+    const uint64_t l = ((k >> pk.bN) & ((1ull << pk.bL) - 1ull)) + pk.min_left;
+    const uint64_t len = k & ((1ull << pk.bN) - 1ull);
+    ckL[p] = (seg << 32) | l;
+    ckR[p] = (seg << 32) | (l + len);
+}
+
+__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ a, int64_t lo, int64_t hi, uint64_t t) {
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// seg_start[t] = first sweep position whose seg >= t, t in [0, n_seg]
+__global__ void __launch_bounds__(256) seg_table_kernel(const uint64_t* __restrict__ keys, int64_t n, Pack pk,
+                                                        int64_t n_seg, int64_t* __restrict__ seg_start) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_seg) return;
+    seg_start[t] = lower_bound_u64(keys, 0, n, (uint64_t)t << pk.seg_shift());
+}
+
+// row of every sweep position (see header, step 3)
+__global__ void __launch_bounds__(256) rank_rows_kernel(const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ idx, int64_t n, Pack pk,
+                                                        const int64_t* __restrict__ seg_start /* may be null */,
+                                                        uint32_t* __restrict__ srow, int32_t* __restrict__ row_of) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t k = keys[p];
+    const int sh = pk.seg_shift();
+    const uint64_t seg = k >> sh;
+    const uint64_t pos_key = k & ((1ull << sh) - 1ull);
+    const uint64_t other = seg ^ 1ull;
+    int64_t own_start, oth_start, oth_end;
+    if (seg_start) {
+        own_start = seg_start[seg]; oth_start = seg_start[other]; oth_end = seg_start[other + 1];
+    } else {
+        own_start = lower_bound_u64(keys, 0, n, seg << sh);
+        oth_start = lower_bound_u64(keys, 0, n, other << sh);
+        oth_end = lower_bound_u64(keys, oth_start, n, (other + 1) << sh);
+    }
+    // '+' (strand 0) precedes '-' on equal (left, right): '+' counts strictly smaller, '-' counts <=
+    const uint64_t target = (other << sh) | pos_key;
+    const int64_t lb = lower_bound_u64(keys, oth_start, oth_end, (seg & 1ull) ? target + 1 : target);
+    const int64_t chrom_start = own_start < oth_start ? own_start : oth_start;
+    const uint32_t row = (uint32_t)(chrom_start + (p - own_start) + (lb - oth_start));
+    srow[p] = row;
+    row_of[idx[p]] = (int32_t)row;
+}
+
+// ------------------------------------------------------------------ generic (two sorts) path
+__global__ void __launch_bounds__(256) build_keys_kernel(const int32_t* __restrict__ left,
+                                                         const int32_t* __restrict__ right,
+                                                         const int8_t* __restrict__ strand, int64_t n,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((uint64_t)(uint32_t)left[i] << 32) | ((uint64_t)(uint32_t)right[i] << 1) | (uint64_t)(strand[i] & 1);
+    idx[i] = (uint32_t)i;
 }
 
 __global__ void __launch_bounds__(256) gather_chrom_kernel(const int32_t* __restrict__ chrom,
@@ -103,6 +209,7 @@ __global__ void __launch_bounds__(256) sweep_keys_kernel(const uint64_t* __restr
     ckR[p] = s | (uint32_t)rowR[r];
 }
 
+// ------------------------------------------------------------------ neighbour lists
 __global__ void __launch_bounds__(64) blockmax_kernel(const uint64_t* __restrict__ ckR, int64_t n,
                                                       uint64_t* __restrict__ bmax) {
     const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -172,13 +279,22 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const uint64_t* __restr
         }
     }
     if (!FILL) {
+        // one write per block into a per-slot maximum (1024 slots): no same-address atomic storm
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) reach = max(reach, (unsigned)__shfl_xor((int)reach, o));
-        if ((threadIdx.x & 63) == 0 && reach) atomicMax(reach_out, (unsigned long long)reach);
+        __shared__ unsigned wreach[4];
+        if ((threadIdx.x & 63) == 0) wreach[threadIdx.x >> 6] = reach;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned r = max(max(wreach[0], wreach[1]), max(wreach[2], wreach[3]));
+            if (r) atomicMax(&reach_out[blockIdx.x & 1023], (unsigned long long)r);
+        }
     }
 }
 
 inline unsigned grid_for(int64_t n, int threads) { return (unsigned)sd_ceil_div(n, threads); }
+
+inline int bits_for(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
 }  // namespace
 
@@ -205,69 +321,111 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     uint32_t* vA = (uint32_t*)A.alloc(N * 4);
     uint32_t* vB = (uint32_t*)A.alloc(N * 4);
     uint32_t* vC = (uint32_t*)A.alloc(N * 4);
-    int32_t* rowL = (int32_t*)A.alloc(N * 4);
-    int32_t* rowR = (int32_t*)A.alloc(N * 4);
     int64_t* deg = (int64_t*)A.alloc((N + 1) * 8);
-    unsigned long long* red = (unsigned long long*)A.alloc(64);
+    unsigned long long* red = (unsigned long long*)A.alloc(RED_WORDS * 8);
     const int64_t nb64 = sd_ceil_div(n, 64);
     uint64_t* bmax = (uint64_t*)A.alloc((size_t)nb64 * 8);
-    if (!kA || !kB || !kC || !vA || !vB || !vC || !rowL || !rowR || !deg || !red || !bmax) return SDICE_ERR_NOMEM;
+    if (!kA || !kB || !kC || !vA || !vB || !vC || !deg || !red || !bmax) return SDICE_ERR_NOMEM;
 
-    // ---- keys + varying-bit masks
-    ctx->h_pinned[0] = 0; ctx->h_pinned[1] = -1; ctx->h_pinned[2] = 0; ctx->h_pinned[3] = -1; ctx->h_pinned[4] = 0;
-    ctx->h_pinned[5] = 0;   // red[5]: max row distance to a neighbour
-    SD_HIP(hipMemcpyAsync(red, ctx->h_pinned, 48, hipMemcpyHostToDevice, ctx->stream));
+    // ---- field ranges (and validation) in one pass, one read-back
+    int64_t* hp = ctx->h_pinned;
+    for (int i = 0; i < RED_WORDS; ++i) hp[i] = 0;
+    hp[1] = -1; hp[3] = -1; hp[6] = -1;   // AND / min identities
+    SD_HIP(hipMemcpyAsync(red, hp, RED_WORDS * 8, hipMemcpyHostToDevice, ctx->stream));
     {
-        int64_t blocks = sd_ceil_div(n, 256);
-        if (blocks > 1024) blocks = 1024;
-        SD_LAUNCH(ctx, "build_keys_kernel", build_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, d_chrom, d_left,
-                  d_right, d_strand, n, kA, vA, red);
+        // few blocks: every block ends with 8 atomics on the same cache line
+        int64_t blocks = sd_ceil_div(n, 256 * 16);
+        if (blocks > 128) blocks = 128;
+        SD_LAUNCH(ctx, "reduce_fields_kernel", reduce_fields_kernel, dim3((unsigned)blocks), dim3(256), 0, d_chrom, d_left,
+                  d_right, d_strand, n, red);
     }
-    SD_HIP(hipMemcpyAsync(ctx->h_pinned + 8, red, 40, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipMemcpyAsync(hp + 16, red, RED_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t maskQ = (uint64_t)ctx->h_pinned[8] ^ (uint64_t)ctx->h_pinned[9];
-    const uint64_t maskC = ((uint64_t)ctx->h_pinned[10] ^ (uint64_t)ctx->h_pinned[11]) & 0xffffffffull;
-    if (ctx->h_pinned[12]) {
+    if (hp[16 + 4]) {
         sdice_set_error("sdice_cluster: invalid junction (need 0 <= left <= right, chrom_rank >= 0, strand in {0,1})");
         return SDICE_ERR_ARG;
     }
+    const uint64_t maskQ = (uint64_t)hp[16] ^ (uint64_t)hp[17];
+    const uint64_t maskC = ((uint64_t)hp[18] ^ (uint64_t)hp[19]) & 0xffffffffull;
+    const uint64_t max_chrom = (uint64_t)hp[18];   // the OR of all chrom ranks bounds the maximum from above
+    const uint64_t min_left = (uint64_t)hp[22], max_left = (uint64_t)hp[23], max_len = (uint64_t)hp[24];
 
-    // ---- row order (chrom, left, right, strand): sort by key, then stably by chrom
-    SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vA, kB, vB, kC, vC, maskQ));   // -> kB, vB
-    const uint32_t* perm = vB;
-    if (maskC) {
-        SD_LAUNCH(ctx, "gather_chrom_kernel", gather_chrom_kernel, dim3(grid_for(n, 256)), dim3(256), 0, d_chrom, vB, n,
-                  kA);
-        SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vB, kC, vA, kB, vC, maskC));   // -> kC, vA
-        perm = vA;
+    Pack pk;
+    pk.bN = bits_for(max_len);
+    pk.bL = bits_for(max_left - min_left);
+    pk.min_left = (uint32_t)min_left;
+    const int bS = bits_for((max_chrom << 1) | 1ull);
+    // 62: (n_seg + 1) << seg_shift must not overflow in the segment table
+    const bool packed = (pk.bN + pk.bL + bS <= 62) && !ctx->param("cluster.generic", 0);
+
+    uint32_t* srow;
+    uint64_t *ckL, *ckR, *pmax;
+    if (packed) {
+        SD_LAUNCH(ctx, "pack_keys_kernel", pack_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, d_chrom, d_left, d_right,
+                  d_strand, n, pk, kA, vA);
+        const int total_bits = pk.bN + pk.bL + bS;
+        const uint64_t mask = total_bits >= 64 ? ~0ull : ((1ull << total_bits) - 1ull);
+        SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vA, kB, vB, kC, vC, mask));   // -> kB (keys), vB (input index)
+        ckL = kA; ckR = kC;
+        SD_LAUNCH(ctx, "decode_keys_kernel", decode_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, kB, n, pk, ckL, ckR);
+        const int64_t n_seg = (int64_t)(((max_chrom << 1) | 1ull) + 1ull);   // seg values are < n_seg
+        int64_t* seg_start = nullptr;
+        if (n_seg <= (1 << 20)) {
+            seg_start = (int64_t*)A.alloc((size_t)(n_seg + 2) * 8);
+            if (!seg_start) return SDICE_ERR_NOMEM;
+            SD_LAUNCH(ctx, "seg_table_kernel", seg_table_kernel, dim3(grid_for(n_seg + 2, 256)), dim3(256), 0, kB, n, pk,
+                      n_seg + 1, seg_start);
+        }
+        srow = vA;
+        SD_LAUNCH(ctx, "rank_rows_kernel", rank_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, kB, vB, n, pk,
+                  (const int64_t*)seg_start, srow, d_row_of);
+        pmax = kB;   // the sorted keys are dead after rank_rows (stream order)
+    } else {
+        int32_t* rowL = (int32_t*)A.alloc(N * 4);
+        int32_t* rowR = (int32_t*)A.alloc(N * 4);
+        if (!rowL || !rowR) return SDICE_ERR_NOMEM;
+        SD_LAUNCH(ctx, "build_keys_kernel", build_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, d_left, d_right,
+                  d_strand, n, kA, vA);
+        // row order (chrom, left, right, strand): sort by key, then stably by chrom
+        SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vA, kB, vB, kC, vC, maskQ));   // -> kB, vB
+        const uint32_t* perm = vB;
+        if (maskC) {
+            SD_LAUNCH(ctx, "gather_chrom_kernel", gather_chrom_kernel, dim3(grid_for(n, 256)), dim3(256), 0, d_chrom, vB, n,
+                      kA);
+            SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vB, kC, vA, kB, vC, maskC));   // -> kC, vA
+            perm = vA;
+        }
+        // per-row data, then sweep order (chrom, strand, left, right) by one more stable sort
+        uint64_t* key3 = kA;
+        uint32_t* rid = (perm == vA) ? vB : vA;
+        SD_LAUNCH(ctx, "rows_kernel", rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, perm, d_chrom, d_left, d_right,
+                  d_strand, n, d_row_of, key3, rid, rowL, rowR);
+        const uint64_t mask3 = (maskC << 1) | (maskQ & 1ull);
+        srow = (rid == vA) ? vB : vA;   // perm no longer needed after rows_kernel
+        SD_TRY(sd_radix_sort_pairs(ctx, n, key3, rid, kB, srow, kC, vC, mask3));   // -> kB (seg), srow
+        ckL = kA; ckR = kC;
+        SD_LAUNCH(ctx, "sweep_keys_kernel", sweep_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, kB, srow, rowL, rowR, n,
+                  ckL, ckR);
+        pmax = kB;  // seg dead after sweep_keys
     }
-    // ---- per-row data, then sweep order (chrom, strand, left, right) by one more stable sort
-    uint64_t* key3 = kA;
-    uint32_t* rid = (perm == vA) ? vB : vA;
-    SD_LAUNCH(ctx, "rows_kernel", rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, perm, d_chrom, d_left, d_right,
-              d_strand, n, d_row_of, key3, rid, rowL, rowR);
-    const uint64_t mask3 = (maskC << 1) | (maskQ & 1ull);
-    uint32_t* srow = (rid == vA) ? vB : vA;   // perm no longer needed after rows_kernel
-    SD_TRY(sd_radix_sort_pairs(ctx, n, key3, rid, kB, srow, kC, vC, mask3));   // -> kB (seg), srow
-    uint64_t* seg = kB;
-    uint64_t* ckL = kA;   // key3 dead
-    uint64_t* ckR = kC;
-    SD_LAUNCH(ctx, "sweep_keys_kernel", sweep_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, seg, srow, rowL, rowR, n,
-              ckL, ckR);
-    uint64_t* pmax = kB;  // seg dead after sweep_keys
     SD_TRY(sd_inclusive_max_scan_u64(ctx, n, ckR, pmax));
     SD_LAUNCH(ctx, "blockmax_kernel", blockmax_kernel, dim3((unsigned)nb64), dim3(64), 0, ckR, n, bmax);
 
     // ---- degrees -> row_ptr
+    unsigned long long* reach_slots = (unsigned long long*)A.alloc(1024 * 8);
+    if (!reach_slots) return SDICE_ERR_NOMEM;
+    SD_HIP(hipMemsetAsync(reach_slots, 0, 1024 * 8, ctx->stream));
     SD_HIP(hipMemsetAsync(deg + n, 0, 8, ctx->stream));
     SD_LAUNCH(ctx, "neighbours_count_kernel", (neighbours_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
-              pmax, bmax, srow, n, deg, (const int64_t*)nullptr, (int32_t*)nullptr, red + 5);
+              pmax, bmax, srow, n, deg, (const int64_t*)nullptr, (int32_t*)nullptr, reach_slots);
     SD_TRY(sd_exclusive_scan_i64(ctx, n + 1, deg, d_row_ptr, nullptr));
-    SD_HIP(hipMemcpyAsync(ctx->h_pinned + 16, d_row_ptr + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(hipMemcpyAsync(ctx->h_pinned + 17, red + 5, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipMemcpyAsync(hp + 32, d_row_ptr + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipMemcpyAsync(hp + 64, reach_slots, 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
-    const int64_t nnz = ctx->h_pinned[16];
-    ctx->cluster_reach = (int)ctx->h_pinned[17];
+    const int64_t nnz = hp[32];
+    int64_t reach = 0;
+    for (int i = 0; i < 1024; ++i) reach = hp[64 + i] > reach ? hp[64 + i] : reach;
+    ctx->cluster_reach = (int)reach;
     if (nnz > ctx->col_cap) {
         if (ctx->d_col) (void)hipFree(ctx->d_col);
         ctx->d_col = nullptr;
@@ -283,7 +441,8 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     }
     if (nnz > 0)
         SD_LAUNCH(ctx, "neighbours_fill_kernel", (neighbours_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
-                  pmax, bmax, srow, n, (int64_t*)nullptr, (const int64_t*)d_row_ptr, ctx->d_col, (unsigned long long*)nullptr);
+                  pmax, bmax, srow, n, (int64_t*)nullptr, (const int64_t*)d_row_ptr, ctx->d_col,
+                  (unsigned long long*)nullptr);
     ctx->nnz = nnz;
     if (nnz_out) *nnz_out = nnz;
     return SDICE_OK;

@@ -91,7 +91,7 @@ extern "C" int sdice_ctx_create(int device_ordinal, sdice_ctx** out) {
     snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_pinned, 4096) != hipSuccess) {
+        hipHostMalloc((void**)&ctx->h_pinned, 16384) != hipSuccess) {
         sdice_set_error("sdice_ctx_create: stream/event/pinned allocation failed");
         delete ctx;
         return SDICE_ERR_HIP;
@@ -300,7 +300,7 @@ extern "C" int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms) {
 extern "C" int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value) {
     SD_ARG(ctx && name, "bad arguments");
     static const char* known[] = {"ps.lds_bytes", "ps.tile_rows", "ps.threads", "ps.chunk_cols",
-                                  "ps.xcd_remap", "ps.halo_rows", "sort.bits", "ranksum.variant",
+                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "sort.bits", "ranksum.variant",
                                   "fisher.threads", "fisher.table_max", nullptr};
     for (int i = 0; known[i]; ++i)
         if (strcmp(known[i], name) == 0) {

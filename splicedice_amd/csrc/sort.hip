@@ -17,6 +17,7 @@ namespace {
 
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SCATTER_ROUNDS = 8;   // keys per lane held in registers by the scatter kernel
 
 __global__ void __launch_bounds__(64) radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                                                         int keys_per_chunk, int n_chunks,
@@ -102,12 +103,23 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const uint64_t* __res
     const int64_t beg = (int64_t)chunk * keys_per_chunk;
     const int64_t end = min(n, beg + keys_per_chunk);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    for (int64_t base = beg; base < end; base += 64) {
-        const int64_t i = base + lane;
+    // the whole chunk goes to registers first: one memory round trip per chunk instead of one
+    // per 64 keys (keys_per_chunk <= 64 * SCATTER_ROUNDS)
+    uint64_t rk[SCATTER_ROUNDS];
+    uint32_t rv[SCATTER_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SCATTER_ROUNDS; ++r) {
+        const int64_t i = beg + r * 64 + lane;
+        rk[r] = 0; rv[r] = 0;
+        if (i < end) { rk[r] = keys_in[i]; rv[r] = vals_in[i]; }
+    }
+#pragma unroll
+    for (int r = 0; r < SCATTER_ROUNDS; ++r) {
+        const int64_t i = beg + r * 64 + lane;
+        if (beg + r * 64 >= end) break;
         const bool active = i < end;
-        uint64_t key = 0;
-        uint32_t val = 0;
-        if (active) { key = keys_in[i]; val = vals_in[i]; }
+        const uint64_t key = rk[r];
+        const uint32_t val = rv[r];
         const uint32_t d = (uint32_t)(key >> shift) & (RADIX - 1);
         uint64_t peers = __ballot(active);
 #pragma unroll
@@ -308,10 +320,11 @@ int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, co
         }
         return SDICE_OK;
     }
-    int64_t kpc = sd_ceil_div(n, 2048);
+    // one wave per chunk; a chunk is at most 64 * SCATTER_ROUNDS keys (held in registers)
+    int64_t kpc = sd_ceil_div(n, 4096);
     kpc = sd_ceil_div(kpc, 64) * 64;
-    if (kpc < 256) kpc = 256;
-    if (kpc > 8192) kpc = 8192;
+    if (kpc < 128) kpc = 128;
+    if (kpc > 64 * SCATTER_ROUNDS) kpc = 64 * SCATTER_ROUNDS;
     const int64_t n_chunks = sd_ceil_div(n, kpc);
     uint32_t* hist = (uint32_t*)ctx->arena.alloc((size_t)RADIX * n_chunks * 4);
     uint32_t* bin_total = (uint32_t*)ctx->arena.alloc(RADIX * 4);

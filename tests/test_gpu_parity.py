@@ -44,6 +44,34 @@ def test_cluster_vs_oracle(ctx, n, seed, kw):
         assert np.array_equal(g, w)
 
 
+@pytest.mark.parametrize("generic", [0, 1])
+def test_cluster_paths_and_wide_keys(ctx, generic):
+    """packed single-sort path vs the generic two-sort path; coordinates near 2^31 and chrom
+    ranks up to 2^20 force wide fields (the packed path must refuse keys that do not fit)."""
+    rng = np.random.default_rng(77)
+    n = 4000
+    cr = rng.choice(np.array([0, 1, 7, 1 << 20, (1 << 20) + 1], np.int32), size=n)
+    left = rng.integers(0, 40, size=n).astype(np.int64) * 5000 + rng.choice([0, 2_000_000_000], size=n)
+    right = np.minimum(left + rng.integers(0, 30000, size=n), 2 ** 31 - 1)
+    strand = rng.integers(0, 2, size=n).astype(np.int8)
+    key = np.stack([cr, left, right, strand], axis=1)
+    key = np.unique(key, axis=0)
+    rng.shuffle(key)
+    cr, left, right, strand = key[:, 0].astype(np.int32), key[:, 1].astype(np.int32), key[:, 2].astype(np.int32), key[:, 3].astype(np.int8)
+    want = O.cluster_csr(cr, left, right, strand)
+    ctx.set_param("cluster.generic", generic)
+    try:
+        got = ctx.cluster(cr, left, right, strand)
+        cr2, l2, r2, s2 = synth.make_junctions(9000, 31, n_chrom=7)
+        got2 = ctx.cluster(cr2, l2, r2, s2)
+    finally:
+        ctx.set_param("cluster.generic", 0)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    for g, w in zip(got2, O.cluster_csr(cr2, l2, r2, s2)):
+        assert np.array_equal(g, w)
+
+
 def test_cluster_touching_and_nested(ctx):
     # SURVEY 0.3: (100,200)/(200,300) touch -> neighbours; (201,250) does not overlap (100,200)
     cr = np.zeros(6, np.int32)
