@@ -32,7 +32,8 @@ namespace {
 
 // red[0..1] OR/AND of (left<<32 | right<<1 | strand); red[2..3] OR/AND of chrom; red[4] error flag;
 // red[5] max row reach (filled later); red[6] min left; red[7] max left; red[8] max (right-left)
-constexpr int RED_WORDS = 12;
+constexpr int RED_WORDS = 16;   // one 128-byte line per slot
+constexpr int RED_SLOTS = 32;
 
 __global__ void __launch_bounds__(256) reduce_fields_kernel(const int32_t* __restrict__ chrom,
                                                             const int32_t* __restrict__ left,
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(256) reduce_fields_kernel(const int32_t* __res
             sh[0][0] |= sh[0][k]; sh[1][0] &= sh[1][k]; sh[2][0] |= sh[2][k]; sh[3][0] &= sh[3][k]; sh[4][0] |= sh[4][k];
             sh[6][0] = min(sh[6][0], sh[6][k]); sh[7][0] = max(sh[7][0], sh[7][k]); sh[8][0] = max(sh[8][0], sh[8][k]);
         }
+        red += (blockIdx.x % RED_SLOTS) * RED_WORDS;
         atomicOr(&red[0], sh[0][0]); atomicAnd(&red[1], sh[1][0]);
         atomicOr(&red[2], sh[2][0]); atomicAnd(&red[3], sh[3][0]);
         if (sh[4][0]) atomicOr(&red[4], 1ull);
@@ -322,33 +324,45 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     uint32_t* vB = (uint32_t*)A.alloc(N * 4);
     uint32_t* vC = (uint32_t*)A.alloc(N * 4);
     int64_t* deg = (int64_t*)A.alloc((N + 1) * 8);
-    unsigned long long* red = (unsigned long long*)A.alloc(RED_WORDS * 8);
+    unsigned long long* red = (unsigned long long*)A.alloc(RED_SLOTS * RED_WORDS * 8);
     const int64_t nb64 = sd_ceil_div(n, 64);
     uint64_t* bmax = (uint64_t*)A.alloc((size_t)nb64 * 8);
     if (!kA || !kB || !kC || !vA || !vB || !vC || !deg || !red || !bmax) return SDICE_ERR_NOMEM;
 
     // ---- field ranges (and validation) in one pass, one read-back
+    // every block ends with 8 atomics; RED_SLOTS copies of the accumulators (one 128-B line each,
+    // block b uses slot b % RED_SLOTS) keep them from queueing on one address; the host folds the slots
     int64_t* hp = ctx->h_pinned;
-    for (int i = 0; i < RED_WORDS; ++i) hp[i] = 0;
-    hp[1] = -1; hp[3] = -1; hp[6] = -1;   // AND / min identities
-    SD_HIP(hipMemcpyAsync(red, hp, RED_WORDS * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int s = 0; s < RED_SLOTS; ++s) {
+        int64_t* q = hp + s * RED_WORDS;
+        for (int i = 0; i < RED_WORDS; ++i) q[i] = 0;
+        q[1] = -1; q[3] = -1; q[6] = -1;   // AND / min identities
+    }
+    SD_HIP(hipMemcpyAsync(red, hp, RED_SLOTS * RED_WORDS * 8, hipMemcpyHostToDevice, ctx->stream));
     {
-        // few blocks: every block ends with 8 atomics on the same cache line
-        int64_t blocks = sd_ceil_div(n, 256 * 16);
-        if (blocks > 128) blocks = 128;
+        int64_t blocks = sd_ceil_div(n, 256 * 4);
+        if (blocks > 1024) blocks = 1024;
         SD_LAUNCH(ctx, "reduce_fields_kernel", reduce_fields_kernel, dim3((unsigned)blocks), dim3(256), 0, d_chrom, d_left,
                   d_right, d_strand, n, red);
     }
-    SD_HIP(hipMemcpyAsync(hp + 16, red, RED_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    int64_t* hr = hp + RED_SLOTS * RED_WORDS;
+    SD_HIP(hipMemcpyAsync(hr, red, RED_SLOTS * RED_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
-    if (hp[16 + 4]) {
+    uint64_t f[RED_WORDS];
+    for (int i = 0; i < RED_WORDS; ++i) f[i] = (uint64_t)hr[i];
+    for (int s = 1; s < RED_SLOTS; ++s) {
+        const uint64_t* q = (const uint64_t*)(hr + s * RED_WORDS);
+        f[0] |= q[0]; f[1] &= q[1]; f[2] |= q[2]; f[3] &= q[3]; f[4] |= q[4];
+        f[6] = q[6] < f[6] ? q[6] : f[6]; f[7] = q[7] > f[7] ? q[7] : f[7]; f[8] = q[8] > f[8] ? q[8] : f[8];
+    }
+    if (f[4]) {
         sdice_set_error("sdice_cluster: invalid junction (need 0 <= left <= right, chrom_rank >= 0, strand in {0,1})");
         return SDICE_ERR_ARG;
     }
-    const uint64_t maskQ = (uint64_t)hp[16] ^ (uint64_t)hp[17];
-    const uint64_t maskC = ((uint64_t)hp[18] ^ (uint64_t)hp[19]) & 0xffffffffull;
-    const uint64_t max_chrom = (uint64_t)hp[18];   // the OR of all chrom ranks bounds the maximum from above
-    const uint64_t min_left = (uint64_t)hp[22], max_left = (uint64_t)hp[23], max_len = (uint64_t)hp[24];
+    const uint64_t maskQ = f[0] ^ f[1];
+    const uint64_t maskC = (f[2] ^ f[3]) & 0xffffffffull;
+    const uint64_t max_chrom = f[2];   // the OR of all chrom ranks bounds the maximum from above
+    const uint64_t min_left = f[6], max_left = f[7], max_len = f[8];
 
     Pack pk;
     pk.bN = bits_for(max_len);

@@ -1,0 +1,79 @@
+"""Junction-axis sharding for multi-GPU runs (new; the reference is single-process).
+
+Rows (junctions in output order) are cut into `world` contiguous ranges.  A cut between rows
+r-1 and r is *clean* when no overlap edge crosses it; overlap clusters are gene sized, so a
+clean cut almost always exists within a few rows of the ideal position k*n/world and the
+shard then needs no halo at all.  When none is close enough the shard is extended by the
+rows its owned rows reference (read-only halo); outputs of halo rows are discarded.
+"""
+import numpy as np
+
+
+def clean_cuts(row_ptr, col):
+    """bool[n+1]: cut[r] is True when no CSR edge joins a row < r with a row >= r."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    n = row_ptr.size - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(row_ptr))
+    hi = np.arange(n, dtype=np.int64)
+    lo = np.arange(n, dtype=np.int64)
+    if col.size:
+        np.maximum.at(hi, rows, col)
+        np.minimum.at(lo, rows, col)
+    cut = np.ones(n + 1, dtype=bool)
+    if n:
+        pm = np.maximum.accumulate(hi)                  # furthest row referenced by rows <= r
+        sm = np.minimum.accumulate(lo[::-1])[::-1]      # nearest row referenced by rows >= r
+        cut[1:n] = (pm[:-1] < np.arange(1, n)) & (sm[1:] >= np.arange(1, n))
+    return cut
+
+
+def shard_plan(row_ptr, col, world, max_shift_frac=0.02):
+    """-> list of dicts(own_lo, own_hi, ext_lo, ext_hi), one per rank.
+
+    own_*: rows whose results the rank produces; ext_*: rows it must hold (own + halo).
+    """
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    n = row_ptr.size - 1
+    cut_ok = clean_cuts(row_ptr, col)
+    clean_pos = np.flatnonzero(cut_ok)
+    bounds = [0]
+    for k in range(1, world):
+        ideal = (k * n) // world
+        j = np.searchsorted(clean_pos, ideal)
+        cands = clean_pos[max(0, j - 1): j + 1]
+        best = int(cands[np.argmin(np.abs(cands - ideal))]) if cands.size else ideal
+        if abs(best - ideal) > max(1, int(max_shift_frac * n / world)):
+            best = ideal                                 # no clean cut nearby: keep balance, take a halo
+        bounds.append(max(best, bounds[-1]))
+    bounds.append(n)
+    plan = []
+    for k in range(world):
+        lo, hi = bounds[k], bounds[k + 1]
+        ext_lo, ext_hi = lo, hi
+        if hi > lo:
+            seg = col[row_ptr[lo]:row_ptr[hi]]
+            if seg.size:
+                ext_lo = min(lo, int(seg.min()))
+                ext_hi = max(hi, int(seg.max()) + 1)
+        plan.append(dict(own_lo=lo, own_hi=hi, ext_lo=ext_lo, ext_hi=ext_hi))
+    return plan
+
+
+def local_csr(row_ptr, col, part):
+    """CSR of the rows [ext_lo, ext_hi) with neighbour indices relative to ext_lo.
+
+    Owned rows keep every neighbour (all inside the extended range by construction); halo rows
+    drop neighbours outside it -- their results are never used.
+    """
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    lo, hi = part["ext_lo"], part["ext_hi"]
+    seg = col[row_ptr[lo]:row_ptr[hi]]
+    rows = np.repeat(np.arange(hi - lo, dtype=np.int64), np.diff(row_ptr[lo:hi + 1]))
+    keep = (seg >= lo) & (seg < hi)
+    deg = np.bincount(rows[keep], minlength=hi - lo)
+    rp = np.zeros(hi - lo + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    return rp, (seg[keep] - lo).astype(np.int32)

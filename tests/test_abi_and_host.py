@@ -1,0 +1,196 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sdice.h declares (no compute
+calls), fails loudly without a GPU, and the host-side logic (text parsing, CSR builders,
+shard plan) behaves like the reference's host code."""
+import argparse
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(REPO, "include", "sdice.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdice_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from splicedice_amd import _ffi
+    lib = _ffi.load()
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/sdice.h but not exported"
+        assert s in _ffi.SIGNATURES, f"{s} has no ctypes prototype in _ffi.SIGNATURES"
+    assert set(_ffi.SIGNATURES) == set(syms)
+    assert lib.sdice_version() == 1
+
+
+def test_no_gpu_fails_loudly():
+    """There is no CPU fallback: on a box without a HIP device context creation raises."""
+    import ctypes
+    from splicedice_amd import _ffi
+    lib = _ffi.load()
+    h = ctypes.c_void_p()
+    rc = lib.sdice_ctx_create(0, ctypes.byref(h))
+    if rc == 0:            # running on a GPU box: nothing to check here
+        lib.sdice_ctx_destroy(h)
+        pytest.skip("a HIP device is present")
+    assert rc < 0 and h.value is None
+    assert b"no CPU backend" in lib.sdice_last_error() or b"gfx950" in lib.sdice_last_error()
+    from splicedice_amd.engine import Context, SdiceError
+    with pytest.raises(SdiceError):
+        Context(0)
+
+
+def test_missing_library_message(monkeypatch, tmp_path):
+    from splicedice_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_ffi.SdiceError, match="no CPU fallback"):
+        _ffi.load()
+
+
+# ----------------------------------------------------------------------------------- host logic
+def _quant_args(**over):
+    a = argparse.Namespace(maxLength=50000, minLength=50, minOverhang=5, drim=False, noMultimap=False,
+                           filter="gtag_only", minUnique=5, lowCoverageNan=False, minEntropy=1)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def _manifest(golden_dir, tmp_path):
+    qdir = os.path.join(golden_dir, "quant_c1")
+    out = tmp_path / "manifest.tsv"
+    with open(os.path.join(qdir, "manifest.rel.tsv")) as src, open(out, "w") as dst:
+        for line in src:
+            row = line.rstrip("\n").split("\t")
+            row[1] = os.path.join(qdir, "inputs", row[1])
+            dst.write("\t".join(row) + "\n")
+    return str(out), qdir
+
+
+@pytest.mark.parametrize("variant", ["default", "lowcov_drim", "strict"])
+def test_quant_host_parsing_matches_reference_files(golden_dir, tmp_path, variant):
+    """junction filters + count gathering (host Python) against the reference's _junctions.bed
+    and _inclusionCounts.tsv; the sort here is Python's, the GPU sort is tested under -m gpu."""
+    import json
+    from splicedice_amd import quant, textio
+    manifest_path, qdir = _manifest(golden_dir, tmp_path)
+    exp = os.path.join(qdir, f"expected_{variant}")
+    args = _quant_args(**json.load(open(os.path.join(exp, "args.json"))))
+    manifest = quant.parse_manifest(manifest_path)
+    assert [s.type for s in manifest] == ["splicedicebed", "splicedicebed", "splicedicebed", "SJ", "bed"]
+    junctions = sorted(quant.get_all_junctions(manifest, args))
+    bed = [ln.split("\t")[3] for ln in open(os.path.join(exp, "out_junctions.bed"))]
+    assert [textio.junction_name(j) for j in junctions] == bed
+    index = {j: i for i, j in enumerate(junctions)}
+    counts, low = quant.get_junction_counts(manifest, index, args)
+    with open(os.path.join(exp, "out_inclusionCounts.tsv")) as fh:
+        fh.readline()
+        for line, row in zip(fh, counts):
+            assert line.rstrip("\n").split("\t")[1:] == [str(int(x)) for x in row]
+    if args.lowCoverageNan:
+        ps = [ln.rstrip("\n").split("\t")[1:] for ln in open(os.path.join(exp, "out_allPS.tsv"))][1:]
+        flat = {int(i) for i in low}
+        s = len(manifest)
+        for i in flat:
+            assert ps[i // s][i % s] == "nan"
+
+
+def test_textio_roundtrip_and_ranks():
+    from splicedice_amd import textio
+    j = ("chr10", 5, 99, "-")
+    assert textio.parse_junction_name(textio.junction_name(j)) == j
+    names, cr, left, right, strand = textio.junction_arrays([("chr2", 1, 2, "+"), ("chr10", 3, 4, "-"), ("chr1", 5, 6, "+")])
+    assert names == ["chr1", "chr10", "chr2"] and cr.tolist() == [2, 1, 0] and strand.tolist() == [0, 1, 0]
+    with pytest.raises(ValueError):
+        textio.junction_arrays([("chr1", 5, 2, "+")])
+    with pytest.raises(ValueError):
+        textio.counts_to_int32([[1.5]], "x")
+    assert textio.counts_to_int32([["3", "0"]], "x").tolist() == [[3, 0]]
+
+
+def test_pairwise_exclusion_csr_matches_isin_semantics():
+    from splicedice_amd import pairwise
+    events = ["a", "b", "c", "b"]                       # a repeated event name matches both rows
+    clusters = {"a": ["b", "zzz", "b"], "b": ["a"], "c": []}
+    row_ptr, col = pairwise.exclusion_csr(events, clusters)
+    counts = np.arange(12).reshape(4, 3)
+    for n, e in enumerate(events):
+        want = counts[np.isin(events, clusters[e])].sum(axis=0)      # pairwise_fisher.py:158-160
+        got = counts[col[row_ptr[n]:row_ptr[n + 1]]].sum(axis=0) if row_ptr[n + 1] > row_ptr[n] else np.zeros(3)
+        assert np.array_equal(got, want)
+    with pytest.raises(KeyError):
+        pairwise.exclusion_csr(["nope"], clusters)
+
+
+def test_pairwise_cluster_file_parsing(tmp_path):
+    from splicedice_amd import pairwise
+    f = tmp_path / "c.tsv"
+    f.write_text("e1\te2,e3\ne4\t\ne5\n")
+    assert pairwise.get_clusters(str(f)) == {"e1": ["e2", "e3"], "e4": [], "e5": []}
+
+
+def test_compare_host_helpers(golden_dir):
+    from splicedice_amd import compare_sample_sets as css
+    d = os.path.join(golden_dir, "compare")
+    rows, cols, m = css.read_ps_table(os.path.join(d, "in_allPS.tsv"))
+    assert m.dtype == np.float32 and m.shape == (300, 12) and np.isnan(m[6, :6]).all()
+    g2 = css.samples_from_manifest(os.path.join(d, "m2.tsv"))
+    assert g2[0] == "samp11"
+    assert css.column_indices(g2, cols).tolist() == [6, 7, 8, 9, 10, 11]          # table order, not manifest order
+    assert css.column_indices(["samp0", "not_in_table"], cols).tolist() == [0]
+    annotated, gene_coords, tids = css.read_annotation(os.path.join(d, "anno.gtf"))
+    assert annotated[("chr1", 999, 2002, "+")] == ["GENEA"] and tids[("chr1", 999, 2002, "+")] == ["T1"]
+    assert gene_coords[("chr1", "+")][(900, 2499)] == ["GENEA"]
+
+
+def test_dispatcher_names_and_flags():
+    from splicedice_amd.__main__ import build_parser
+    p = build_parser()
+    a = p.parse_args(["quant", "-m", "m", "-o", "o"])
+    assert (a.maxLength, a.minLength, a.minOverhang, a.minUnique, a.minEntropy, a.filter) == (50000, 50, 5, 5, 1, "gtag_only")
+    a = p.parse_args(["pairwise", "--inclusionSPLICEDICE", "c", "-c", "k"])
+    assert a.multiple_test_correction == "pairwise" and a.output == "pairwise.tsv" and a.chi2 is False
+    a = p.parse_args(["compare_sample_sets", "--psiSPLICEDICE", "p", "-m1", "a", "-m2", "b", "-o", "x"])
+    assert a.annotation == ""
+    a = p.parse_args(["counts_to_ps", "-i", "c", "-o", "o", "-r"])
+    assert a.recluster and a.clusters is None
+    for name in ("bam_to_junc_bed", "intron_coverage", "ir_table", "findOutliers", "subset", "similarity", "select"):
+        assert p.parse_args([name]).command == name
+
+
+# ----------------------------------------------------------------------------------- shard plan
+def test_shard_plan_clean_cuts_and_halo():
+    from oracle import oracle_np as O
+    from splicedice_amd import shard, synth
+    cr, l, r, st = synth.make_junctions(6000, 3, n_chrom=3)
+    _, row_ptr, col = O.cluster_csr(cr, l, r, st)
+    for world in (1, 2, 3, 8):
+        plan = shard.shard_plan(row_ptr, col, world)
+        assert plan[0]["own_lo"] == 0 and plan[-1]["own_hi"] == 6000
+        assert all(plan[k]["own_hi"] == plan[k + 1]["own_lo"] for k in range(world - 1))
+        sizes = [p["own_hi"] - p["own_lo"] for p in plan]
+        assert max(sizes) - min(sizes) <= 0.1 * 6000 / world + 2
+        for p in plan:      # gene-shaped data: clean cut nearby (zero halo) or a halo of a few rows
+            assert 0 <= p["own_lo"] - p["ext_lo"] <= 64 and 0 <= p["ext_hi"] - p["own_hi"] <= 64
+            rp, cl = shard.local_csr(row_ptr, col, p)
+            a, b = p["own_lo"] - p["ext_lo"], p["own_hi"] - p["ext_lo"]
+            seg = col[row_ptr[p["own_lo"]]:row_ptr[p["own_hi"]]]
+            assert np.array_equal(cl[rp[a]:rp[b]], seg - p["ext_lo"])     # owned rows keep every neighbour
+            assert cl.size == 0 or (cl.min() >= 0 and cl.max() < p["ext_hi"] - p["ext_lo"])
+    assert any((p["ext_lo"], p["ext_hi"]) == (p["own_lo"], p["own_hi"]) for p in shard.shard_plan(row_ptr, col, 2))
+    # one chain-linked block has no clean cut: the plan must fall back to halos
+    n = 400
+    row_ptr = np.arange(0, 2 * n + 1, 2, dtype=np.int64)
+    col = np.stack([np.maximum(np.arange(n) - 1, 0), np.minimum(np.arange(n) + 1, n - 1)], axis=1).ravel().astype(np.int32)
+    plan = shard.shard_plan(row_ptr, col, 4)
+    assert [p["own_lo"] for p in plan] == [0, 100, 200, 300]
+    assert plan[1]["ext_lo"] == 99 and plan[1]["ext_hi"] == 201
+    rp, cl = shard.local_csr(row_ptr, col, plan[1])
+    assert rp.size == 103 and cl.min() >= 0 and cl.max() <= 101

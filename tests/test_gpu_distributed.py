@@ -1,0 +1,53 @@
+"""GPU: the sharded quant -> compare pipeline on the real engine (world 1 on the one-GPU box),
+against the oracle, plus the library's RCCL communicator at world size 1."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem():
+    from splicedice_amd import synth
+    n, s = 5000, 24
+    cr, l, r, st = synth.make_junctions(n, 27, n_chrom=3)
+    row_of, row_ptr, col = O.cluster_csr(cr, l, r, st)
+    counts_in = synth.make_counts(n, s, 28, mean=12)
+    counts = np.zeros_like(counts_in)
+    counts[row_of] = counts_in
+    counts[::41] = 0
+    return counts, row_ptr, col, np.arange(0, 12, dtype=np.int32), np.arange(12, 24, dtype=np.int32)
+
+
+def test_sharded_pipeline_on_engine_matches_oracle(ctx):
+    from splicedice_amd import distributed, shard
+    counts, row_ptr, col, g1, g2 = _problem()
+    out = distributed.quant_compare_sharded(ctx, distributed.SingleComm(), counts, row_ptr, col, g1, g2)
+    ps = O.quantize3_fast(O.calculate_psi_vectorised(counts, row_ptr, col)[0])
+    want = O.compare_rows(ps, g1, g2)
+    t = want["tested"].astype(bool)
+    assert np.array_equal(out["tested"], want["tested"]) and np.array_equal(out["z"][t], want["z"][t])
+    for k in ("med1", "med2", "mean1", "mean2", "delta"):
+        assert np.array_equal(out[k][t], want[k][t])
+    np.testing.assert_allclose(out["p"][t], want["p"][t], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(out["corrected"][t], O.bh_fdr(want["p"][t]), rtol=1e-9, atol=0)
+    # every shard of a 4-way plan, computed one after the other on this GPU, reproduces its rows
+    plan = shard.shard_plan(row_ptr, col, 4)
+    for part in plan:
+        rp, cl = shard.local_csr(row_ptr, col, part)
+        loc = ctx.ps(counts[part["ext_lo"]:part["ext_hi"]], rp, cl)
+        a, b = part["own_lo"] - part["ext_lo"], part["own_hi"] - part["ext_lo"]
+        full = O.calculate_psi_vectorised(counts, row_ptr, col)[0]
+        assert np.array_equal(loc[a:b], full[part["own_lo"]:part["own_hi"]], equal_nan=True)
+
+
+def test_rccl_world1_allgather():
+    """own context: the communicator lives and dies with it"""
+    from splicedice_amd.engine import Context
+    from splicedice_amd import distributed
+    with Context(0) as c:
+        comm = distributed.RcclComm(c, 0, 1, lambda b, n: b)
+        table = np.arange(40, dtype=np.float64).reshape(5, 8)
+        got = comm.allgather_rows(table)
+        assert len(got) == 1 and np.array_equal(got[0], table)
