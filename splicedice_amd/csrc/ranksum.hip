@@ -42,9 +42,9 @@ __device__ __forceinline__ void rs_finish(int nv1, int nv2, long long u2, double
     const double num = 0.5 * (double)(u2 - (long long)nv1 * (long long)nv2);
     const double den = sqrt((double)((long long)nv1 * nv2 * (nv1 + nv2 + 1)) / 12.0);
     z = num / den;
-    const double x = -fabs(z) * 0.70710678118654752440;  // cephes ndtr(-|z|)
-    const double y = (fabs(x) < 0.70710678118654752440) ? 0.5 + 0.5 * erf(x) : 0.5 * erfc(-x);
-    p = 2.0 * y;
+    // scipy: p = 2 * ndtr(-|z|); cephes ndtr evaluates 0.5*erfc(|z|/sqrt2) for |z| >= 1 and
+    // 0.5 + 0.5*erf(-|z|/sqrt2) below, i.e. erfc(|z|/sqrt2) up to one rounding of a value >= 0.3
+    p = erfc(fabs(z) * 0.70710678118654752440);
 }
 
 // ------------------------------------------------------------------ lane-per-row variant
@@ -59,8 +59,11 @@ __device__ __forceinline__ void bitonic_regs(float (&a)[P]) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool asc = (i & k) == 0;
-                    const float lo = __builtin_fminf(a[i], a[l]);
-                    const float hi = __builtin_fmaxf(a[i], a[l]);
+                    // plain v_min/v_max: no NaN reaches the network (compaction removed them), and
+                    // fminf/fmaxf would add a canonicalising v_max per operand
+                    float lo, hi;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a[i]), "v"(a[l]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a[i]), "v"(a[l]));
                     a[i] = asc ? lo : hi;
                     a[l] = asc ? hi : lo;
                 }
@@ -74,13 +77,16 @@ __device__ __forceinline__ void bitonic_regs(float (&a)[P]) {
 // valid values, the float32 pairwise mean, and leaves the group SORTED in row[0..nv).
 template <int P>
 __device__ __forceinline__ int lane_group(float* row, int cnt, float& mean) {
-    int nv = 0;
-    for (int k = 0; k < cnt; ++k) {
-        const float x = row[k];
-        if (x == x) { row[nv] = x; ++nv; }
-    }
+    // all LDS reads first (independent, pipelined), then the in-place compaction is a chain of
+    // stores whose only dependency is the integer counter, then one more batch of reads
     float a[P];
     const float inf = __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < P; ++k) a[k] = (k < cnt) ? row[k] : __builtin_nanf("");
+    int nv = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        if (a[k] == a[k]) { row[nv] = a[k]; ++nv; }
 #pragma unroll
     for (int k = 0; k < P; ++k) a[k] = (k < nv) ? row[k] : inf;
     // numpy pairwise_sum (n <= 128 -> single block), npy loops_utils.h.src
@@ -118,61 +124,97 @@ __device__ __forceinline__ float median_sorted(const float* a, int nv) {
     return (a[h - 1] + a[h]) / 2.0f;
 }
 
-template <int P1, int P2>
+template <int P>
 __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restrict__ ps, int64_t n, int s,
                                                            const int32_t* __restrict__ gsel, int n1, int n2,
-                                                           int stride, RsOut o) {
+                                                           int stride, RsOut o, int ablate) {
     extern __shared__ float smemf[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     float* tile = smemf + (size_t)wave * 64 * stride;
     const int nsel = n1 + n2;
+    int* selL = reinterpret_cast<int*>(smemf + (size_t)waves_per_block * 64 * stride);
+    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    __syncthreads();
     const int64_t n_groups = (n + 63) >> 6;
     for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
          g += (int64_t)gridDim.x * waves_per_block) {
         const int64_t row0 = g << 6;
-        // ---- stage 64 rows x nsel selected columns (coalesced along the row)
+        // ---- stage 64 rows x nsel selected columns.  Lane l owns selected columns l and l + 64
+        // for every row, so a row is one or two coalesced wave loads with a 32-bit offset that
+        // advances by s per row (no per-element index arithmetic); 16 rows are in flight at once.
         {
-            int r = lane / nsel, k = lane - r * nsel;
-            const int dr = 64 / nsel, dk = 64 - dr * nsel;
-            const int total = 64 * nsel;
-            for (int e = lane; e < total; e += 64) {
-                const int64_t row = row0 + r;
-                float x = __builtin_nanf("");
-                if (row < n) x = ps[row * s + gsel[k]];
-                tile[r * stride + k] = x;
-                k += dk; r += dr;
-                if (k >= nsel) { k -= nsel; r += 1; }
+            const int rows_avail = (int)min((int64_t)64, n - row0);
+            const float* gbase = ps + row0 * s;
+            const bool act0 = lane < nsel, act1 = lane + 64 < nsel;
+            const int sel0 = act0 ? selL[lane] : 0;
+            const int sel1 = act1 ? selL[lane + 64] : 0;
+            constexpr int RB = 16;
+            for (int r0 = 0; r0 < 64; r0 += RB) {
+                float x0[RB], x1[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int rc = min(r0 + q, rows_avail - 1);       // rows past the end re-read the last row
+                    x0[q] = act0 ? gbase[rc * s + sel0] : 0.f;
+                    x1[q] = act1 ? gbase[rc * s + sel1] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = r0 + q;
+                    const bool live = r < rows_avail;
+                    if (act0) tile[r * stride + lane] = live ? x0[q] : __builtin_nanf("");
+                    if (act1) tile[r * stride + lane + 64] = live ? x1[q] : __builtin_nanf("");
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         // ---- per-lane serial work on row (row0 + lane)
         float* row = tile + lane * stride;
-        float mean1, mean2;
-        const int nv1 = lane_group<P1>(row, n1, mean1);
-        const int nv2 = lane_group<P2>(row + n1, n2, mean2);
+        // both groups go through ONE copy of the (fully unrolled, register resident) group code:
+        // two inlined copies of the 64-wide network do not fit the instruction cache
+        float mean1 = 0.f, mean2 = 0.f;
+        int nv1 = 0, nv2 = 0;
+#pragma nounroll
+        for (int gi = 0; gi < ((ablate & 2) ? 0 : 2); ++gi) {
+            float m;
+            const int nv = lane_group<P>(row + (gi ? n1 : 0), gi ? n2 : n1, m);
+            if (gi == 0) { nv1 = nv; mean1 = m; } else { nv2 = nv; mean2 = m; }
+        }
         const int64_t rr = row0 + lane;
         if (rr < n) {
             const bool tested = nv1 >= 3 && nv2 >= 3;
             float med1 = 0.f, med2 = 0.f, dl = 0.f;
             double z = 0.0, p = 0.0;
-            if (tested) {
+            if (tested && !(ablate & 1)) {
                 const float* A = row;
                 const float* B = row + n1;
                 med1 = median_sorted(A, nv1);
                 med2 = median_sorted(B, nv2);
                 dl = med1 - med2;
-                // 2U by a two-pointer merge of the sorted groups
+                // 2U = sum_i (lb_i + ub_i) = sum_i (2 ub_i - eq_i) by ONE sequential merge with a
+                // fixed trip count nv1 + nv2 (no nested data-dependent loops: lanes stay in step).
+                // Rule: take b while b <= a.  When a_i is taken, j = #{b <= a_i} = ub_i, and the
+                // run of equal b's taken last tells eq_i = #{b == a_i}.
                 long long u2 = 0;
-                int jl = 0, je = 0;
-                for (int i = 0; i < nv1; ++i) {
-                    const float ai = A[i];
-                    while (jl < nv2 && B[jl] < ai) ++jl;
-                    if (je < jl) je = jl;
-                    while (je < nv2 && B[je] <= ai) ++je;
-                    u2 += jl + je;
+                int i = 0, j = 0, run_len = 0;
+                float run_val = 0.f;
+                float av = A[0], bv = B[0];
+                const int steps = nv1 + nv2;
+                for (int t = 0; t < steps; ++t) {
+                    const bool take_b = j < nv2 && (i >= nv1 || bv <= av);
+                    if (take_b) {
+                        run_len = (run_len > 0 && bv == run_val) ? run_len + 1 : 1;
+                        run_val = bv;
+                        ++j;
+                        bv = B[j < nv2 ? j : nv2 - 1];
+                    } else {
+                        const int eq = (run_len > 0 && run_val == av) ? run_len : 0;
+                        u2 += 2 * j - eq;
+                        ++i;
+                        av = A[i < nv1 ? i : nv1 - 1];
+                    }
                 }
                 rs_finish(nv1, nv2, u2, z, p);
             } else {
@@ -391,31 +433,20 @@ __global__ void __launch_bounds__(RB_THREADS) ranksum_block_kernel(const float* 
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-template <int P1, int P2>
+template <int P>
 int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2, RsOut o) {
     const int stride = (n1 + n2) | 1;
     int waves = 2;
-    const size_t lds = (size_t)waves * 64 * stride * 4;
+    const size_t lds = (size_t)waves * 64 * stride * 4 + (size_t)(n1 + n2) * 4;
     int64_t groups = sd_ceil_div(n, 64);
     int64_t blocks = sd_ceil_div(groups, waves);
     const int64_t cap = (int64_t)ctx->n_cu * 16;
     if (blocks > cap) blocks = cap;
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_lane_kernel<P1, P2>),
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_lane_kernel<P>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "ranksum_lane_kernel", (ranksum_lane_kernel<P1, P2>), dim3((unsigned)blocks), dim3(waves * 64), lds,
-              d_ps, n, s, gsel, n1, n2, stride, o);
+    SD_LAUNCH(ctx, "ranksum_lane_kernel", (ranksum_lane_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
+              s, gsel, n1, n2, stride, o, (int)ctx->param("ranksum.ablate", 0));
     return SDICE_OK;
-}
-
-template <int P1>
-int dispatch_lane_p2(sdice_ctx* ctx, int p2, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2,
-                     RsOut o) {
-    switch (p2) {
-        case 8: return launch_lane<P1, 8>(ctx, d_ps, n, s, gsel, n1, n2, o);
-        case 16: return launch_lane<P1, 16>(ctx, d_ps, n, s, gsel, n1, n2, o);
-        case 32: return launch_lane<P1, 32>(ctx, d_ps, n, s, gsel, n1, n2, o);
-        default: return launch_lane<P1, 64>(ctx, d_ps, n, s, gsel, n1, n2, o);
-    }
 }
 
 }  // namespace
@@ -450,12 +481,12 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         if (!gsel) return SDICE_ERR_NOMEM;
         SD_HIP(hipMemcpyAsync(gsel, d_g1, (size_t)n1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         SD_HIP(hipMemcpyAsync(gsel + n1, d_g2, (size_t)n2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        int p1 = next_pow2(n1 < 8 ? 8 : n1), p2 = next_pow2(n2 < 8 ? 8 : n2);
-        switch (p1) {
-            case 8: return dispatch_lane_p2<8>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
-            case 16: return dispatch_lane_p2<16>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
-            case 32: return dispatch_lane_p2<32>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
-            default: return dispatch_lane_p2<64>(ctx, p2, d_ps, n, s, gsel, n1, n2, o);
+        const int big = n1 > n2 ? n1 : n2;
+        switch (next_pow2(big < 8 ? 8 : big)) {
+            case 8: return launch_lane<8>(ctx, d_ps, n, s, gsel, n1, n2, o);
+            case 16: return launch_lane<16>(ctx, d_ps, n, s, gsel, n1, n2, o);
+            case 32: return launch_lane<32>(ctx, d_ps, n, s, gsel, n1, n2, o);
+            default: return launch_lane<64>(ctx, d_ps, n, s, gsel, n1, n2, o);
         }
     }
     const int P1 = next_pow2(n1), P2 = next_pow2(n2);
