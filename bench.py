@@ -51,8 +51,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["quant", "compare", "pairwise"], default="quant")
-    ap.add_argument("--n", type=int, default=0, help="junctions per GPU (default: the BASELINE config)")
-    ap.add_argument("--s", type=int, default=0, help="samples (default: the BASELINE config)")
+    # (long names only: under torch.distributed.run a short "--n" is swallowed by the launcher's parser)
+    ap.add_argument("--junctions", dest="n", type=int, default=0, help="junctions per GPU (default: the BASELINE config)")
+    ap.add_argument("--samples", dest="s", type=int, default=0, help="samples (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="junctions in the CPU-baseline sample")
     ap.add_argument("--no-verify", action="store_true")
@@ -302,8 +303,16 @@ def traffic_from_profiles(workload, n, s):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line (the JSON): gloo / RCCL print banners on fd 1, so fd 1 is
+    # pointed at stderr for the whole run and the JSON goes to a saved copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist = Dist(args.gpus)
-    ctx = Context(dist.local_rank if args.gpus > 1 else 0)
+    # one rank per GPU; SDICE_BENCH_DEVICE pins every rank to one device (rehearsing the N>1 control
+    # flow on a one-GPU box -- RCCL then refuses the duplicate GPU and "allgather" reports it)
+    forced = os.environ.get("SDICE_BENCH_DEVICE")
+    ctx = Context(int(forced) if forced is not None else (dist.local_rank if args.gpus > 1 else 0))
     wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
 
     for _ in range(args.warmup):
@@ -372,7 +381,7 @@ def main():
             "cpu_baseline": cpu, "verify": verify, "allgather": allgather,
             "device": info["name"].strip(), "gen_seconds": round(wl.gen_s, 1),
         }
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     dist.close()
     ctx.close()
 

@@ -45,6 +45,7 @@ struct PsArgs {
     int col_cap;     // LDS capacity for staged neighbour offsets (ints)
     int n_tiles;
     int tiles_per_xcd;  // 0 = no remap
+    int ablate;         // timing experiments only: 1 skip gather, 2 skip staging loads, 4 skip stores
 };
 
 template <int VEC> struct Vt;
@@ -97,7 +98,7 @@ template <int VEC, typename ACC> __device__ __forceinline__ void store_excl(int6
 template <int VEC, bool FAST, bool WEXCL, bool WPS>
 __device__ __forceinline__ bool ps_item(const PsArgs& a, const char* tileB, const int* colL, bool col_in_lds,
                                         int64_t kbase, int k0, int k1, int slo, int wrows, int ldw, int c0, int cvec,
-                                        int own_row, int64_t out_index, unsigned thr) {
+                                        int own_row, int64_t out_index, unsigned thr, int zero_off) {
     typedef typename Vt<VEC>::I VI;
     typedef typename std::conditional<FAST, unsigned, unsigned long long>::type ACC;
     ACC acc[VEC];
@@ -105,20 +106,49 @@ __device__ __forceinline__ bool ps_item(const PsArgs& a, const char* tileB, cons
     for (int q = 0; q < VEC; ++q) acc[q] = 0;
     bool ok = true;
     const int cbytes = cvec * 4;
-    for (int k = k0; k < k1; ++k) {
-        int off;
-        if (col_in_lds) {
-            off = colL[k];
-        } else {
-            const int j = a.col[kbase + k];
-            const unsigned rel = (unsigned)(j - slo);
-            off = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
+    int k = k0;
+    if (col_in_lds) {
+        // batches of GB neighbours: all offset reads, then all row reads, then the adds -- two LDS
+        // round trips per batch instead of two per neighbour; short batches are padded with the
+        // all-zero row kept behind the window
+        constexpr int GB = 4;
+        for (; k < k1; k += GB) {
+            int off[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) off[u] = (k + u < k1) ? colL[k + u] : zero_off;
+            int mn = off[0];
+#pragma unroll
+            for (int u = 1; u < GB; ++u) mn = min(mn, off[u]);
+            if (mn >= 0) {
+                VI v[GB];
+#pragma unroll
+                for (int u = 0; u < GB; ++u) v[u] = *reinterpret_cast<const VI*>(tileB + off[u] + cbytes);
+#pragma unroll
+                for (int u = 0; u < GB; ++u) acc_add(acc, v[u]);
+            } else {
+                // a neighbour outside the staged window: global-memory path
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                    VI v;
+                    if (off[u] >= 0) {
+                        v = *reinterpret_cast<const VI*>(tileB + off[u] + cbytes);
+                    } else {
+                        const int j = -1 - off[u];
+                        v = *reinterpret_cast<const VI*>(a.counts + (int64_t)j * a.s + c0 + cvec);
+                        if (FAST && vmax(v) > thr) ok = false;
+                    }
+                    acc_add(acc, v);
+                }
+            }
         }
+    }
+    for (; k < k1; ++k) {      // neighbour list too long for the LDS stage: indices from global memory
+        const int j = a.col[kbase + k];
+        const unsigned rel = (unsigned)(j - slo);
         VI v;
-        if (off >= 0) {
-            v = *reinterpret_cast<const VI*>(tileB + off + cbytes);
+        if (rel < (unsigned)wrows) {
+            v = *reinterpret_cast<const VI*>(tileB + rel * (unsigned)ldw * 4u + cbytes);
         } else {
-            const int j = -1 - off;
             v = *reinterpret_cast<const VI*>(a.counts + (int64_t)j * a.s + c0 + cvec);
             if (FAST && vmax(v) > thr) ok = false;
         }
@@ -131,7 +161,7 @@ __device__ __forceinline__ bool ps_item(const PsArgs& a, const char* tileB, cons
 #pragma unroll
         for (int q = 0; q < VEC; ++q)
             o[q] = FAST ? ps_value32(comp(own, q), (unsigned)acc[q]) : ps_value64(comp(own, q), (unsigned long long)acc[q]);
-        store_f<VEC>(a.ps + out_index, o);
+        if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
     }
     if (WEXCL) store_excl<VEC, ACC>(a.excl + out_index, acc);
     return true;
@@ -143,7 +173,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     extern __shared__ int4 smem4[];
     const int win_cap = a.tile_rows + 2 * a.halo;
     int* tileL = reinterpret_cast<int*>(smem4);
-    int* colL = tileL + (size_t)win_cap * a.chunk_cols;
+    int* colL = tileL + (size_t)(win_cap + 1) * a.chunk_cols;   // row win_cap is the all-zero padding row
     int* rpL = colL + a.col_cap;
     unsigned* red = reinterpret_cast<unsigned*>(rpL + a.tile_rows + 1);  // [0] max count, [1] max degree
 
@@ -166,6 +196,8 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     const int shi = (int)min(a.n, r0 + nr + a.halo);
     const int wrows = shi - slo;
     if (tid < 2) red[tid] = 0u;
+    for (int i = tid; i < a.chunk_cols; i += T) tileL[(size_t)win_cap * a.chunk_cols + i] = 0;
+    const int zero_off = win_cap * a.chunk_cols * 4;
 
     // ---- CSR row pointers of the tile (their loads go out first, the data loads right behind)
     int64_t rp_mine[2];
@@ -181,6 +213,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
             const VI* g = reinterpret_cast<const VI*>(a.counts + (int64_t)slo * a.s);
             VI* l = reinterpret_cast<VI*>(tileL);
             int i = tid;
+            if (a.ablate & 2) i = total;
             for (; i + 3 * T < total; i += 4 * T) {
                 const VI v0 = g[i], v1 = g[i + T], v2 = g[i + 2 * T], v3 = g[i + 3 * T];
                 l[i] = v0; l[i + T] = v1; l[i + 2 * T] = v2; l[i + 3 * T] = v3;
@@ -234,15 +267,15 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
         const int dr = T / V, dc = T - dr * V;
         const int own_base = (int)(r0 - slo);
         for (int it = tid; it < items; it += T) {
-            const int k0 = rpL[ri], k1 = rpL[ri + 1];
+            const int k0 = rpL[ri], k1 = (a.ablate & 1) ? k0 : rpL[ri + 1];
             const int64_t o = (r0 + ri) * a.s + c0 + c * VEC;
             bool done = false;
             if (fast)
                 done = ps_item<VEC, true, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0,
-                                                      c * VEC, own_base + ri, o, thr);
+                                                      c * VEC, own_base + ri, o, thr, zero_off);
             if (!done)
                 ps_item<VEC, false, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
-                                                own_base + ri, o, thr);
+                                                own_base + ri, o, thr, zero_off);
             c += dc; ri += dr;
             if (c >= V) { c -= V; ri += 1; }
         }
@@ -335,17 +368,17 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
             H = ctx->cluster_reach;
     }
     int64_t R = ctx->param("ps.tile_rows", 0);
-    if (R <= 0) R = (L - 2 * H * cw) / (cw + 17);
+    if (R <= 0) R = (L - (2 * H + 1) * cw) / (cw + 17);
     if (R > 2 * threads) R = 2 * threads;   // the kernel keeps two row pointers per thread in registers
-    while (H > 0 && (R < 8 || (R + 2 * H) * cw + 17 * R > L)) {
+    while (H > 0 && (R < 8 || (R + 2 * H + 1) * cw + 17 * R > L)) {
         // window does not fit: shrink the halo first (misses fall back to global loads), then the tile
         H = H / 2;
-        if (ctx->param("ps.tile_rows", 0) <= 0) R = (L - 2 * H * cw) / (cw + 17);
+        if (ctx->param("ps.tile_rows", 0) <= 0) R = (L - (2 * H + 1) * cw) / (cw + 17);
         if (R > 2 * threads) R = 2 * threads;
     }
     if (R < 1) R = 1;
-    while (R > 1 && (R + 2 * H) * cw + 17 * R > L) R -= 1;
-    SD_ARG((R + 2 * H) * cw + 17 * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
+    while (R > 1 && (R + 2 * H + 1) * cw + 17 * R > L) R -= 1;
+    SD_ARG((R + 2 * H + 1) * cw + 17 * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
     if (R > n) { R = n; }
 
     PsArgs a;
@@ -360,6 +393,7 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     SD_ARG(n_chunks <= 65535, "too many column chunks");
     int gx = a.n_tiles;
     a.tiles_per_xcd = 0;
+    a.ablate = (int)ctx->param("ps.ablate", 0);
     if (ctx->param("ps.xcd_remap", 1) && a.n_tiles >= 64) {
         a.tiles_per_xcd = (int)sd_ceil_div(a.n_tiles, 8);
         gx = a.tiles_per_xcd * 8;
