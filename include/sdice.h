@@ -135,6 +135,15 @@ int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* 
 /* m independent 2x2 tables abcd[m,4] int64 -> p[m] (same kernel math; KAT entry point) */
 int sdice_fisher_tables(sdice_ctx* ctx, int64_t m, const int64_t* abcd, double* p);
 
+/* pairwise --chi2: replaces test_method = scipy.stats.chi2_contingency (pairwise_fisher.py:133-136,
+ * :179): Yates-corrected 2x2 chi-square, p = chdtrc(1, chi2).  scipy raises ValueError on a zero
+ * expected frequency (the reference run aborts); such tables get p = NaN and are counted in *n_bad
+ * so that the caller can raise.  Same shapes and pair order as sdice_fisher_pairs. */
+int sdice_chi2_pairs(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* incl,
+                     const int64_t* excl, double* p, int64_t* n_bad);
+int sdice_chi2_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* d_incl,
+                         const int64_t* d_excl, double* d_p, int64_t* d_n_bad /* device */);
+
 /* ---- Benjamini-Hochberg: replaces statsmodels multipletests(p, method="fdr_bh")[1]
  *      (compareSampleSets.py:235; pairwise_fisher.py:185,190). */
 int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q);

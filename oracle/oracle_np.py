@@ -322,6 +322,39 @@ def fisher_pairs(incl, excl, use_scipy=True):
     return out
 
 
+def chi2_yates_restated(a, b, c, d):
+    """p of scipy.stats.chi2_contingency([[a,b],[c,d]]) (contingency.py, 1.15.3; pairwise --chi2,
+    pairwise_fisher.py:133-136): Yates-corrected Pearson chi-square, dof 1, p = chdtrc(1, chi2).
+    Raises ValueError on a zero expected frequency, as scipy does."""
+    obs = np.array([[a, b], [c, d]], dtype=np.float64)
+    tot = obs.sum()
+    exp = np.outer(obs.sum(axis=1), obs.sum(axis=0)) / tot if tot > 0 else np.zeros((2, 2))
+    if (exp == 0).any():
+        raise ValueError("The internally computed table of expected frequencies has a zero element")
+    diff = exp - obs
+    obs = obs + np.minimum(0.5, np.abs(diff)) * np.sign(diff)
+    stat = (((obs - exp) ** 2) / exp).sum()
+    return math.erfc(math.sqrt(0.5 * stat))
+
+
+def chi2_pairs(incl, excl, use_scipy=True):
+    """pairwise --chi2: p[n, s(s-1)/2]; ValueError as scipy raises it."""
+    if use_scipy:
+        from scipy.stats import chi2_contingency
+    incl = np.asarray(incl)
+    excl = np.asarray(excl)
+    n, s = incl.shape
+    pairs = pair_list(s)
+    out = np.empty((n, len(pairs)), dtype=np.float64)
+    for r in range(n):
+        for q, (i, j) in enumerate(pairs):
+            if use_scipy:
+                out[r, q] = chi2_contingency([[incl[r, i], incl[r, j]], [excl[r, i], excl[r, j]]])[1]
+            else:
+                out[r, q] = chi2_yates_restated(incl[r, i], incl[r, j], excl[r, i], excl[r, j])
+    return out
+
+
 def bh_columns(p):
     """pairwise_fisher.py:187-191: BH down each pair column."""
     p = np.array(p, dtype=np.float64)

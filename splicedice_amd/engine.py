@@ -192,6 +192,15 @@ class Context:
         check(self.lib.sdice_fisher_pairs(self.h, n, s, _ptr(incl), _ptr(excl), _ptr(p)), "sdice_fisher_pairs")
         return p
 
+    def chi2_pairs(self, incl, excl):
+        """pairwise --chi2 (scipy chi2_contingency per pair) -> (p float64[n, s(s-1)/2], n_bad)"""
+        incl, excl = _c(incl, np.int32), _c(excl, np.int64)
+        n, s = incl.shape
+        p = np.empty((n, s * (s - 1) // 2), dtype=np.float64)
+        bad = C.c_int64()
+        check(self.lib.sdice_chi2_pairs(self.h, n, s, _ptr(incl), _ptr(excl), _ptr(p), C.byref(bad)), "sdice_chi2_pairs")
+        return p, bad.value
+
     def fisher_tables(self, abcd):
         abcd = _c(abcd, np.int64).reshape(-1, 4)
         p = np.empty(abcd.shape[0], dtype=np.float64)

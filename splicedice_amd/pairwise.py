@@ -5,8 +5,8 @@ same stdout lines, same output table `clusterID <a_b columns>` with str(float64)
 
 On the GPU: the exclusion gather :158-160 (an O(N) name scan per event in the reference)
 -> sdice_ps (integer sums over a CSR built once on the host from the name lists); the per-pair
-scipy fisher_exact :164-179 -> sdice_fisher_pairs; Benjamini-Hochberg :182-193 -> sdice_bh /
-sdice_bh_columns.
+scipy fisher_exact :164-179 -> sdice_fisher_pairs (or, with --chi2, chi2_contingency :133-136 ->
+sdice_chi2_pairs); Benjamini-Hochberg :182-193 -> sdice_bh / sdice_bh_columns.
 """
 import numpy as np
 
@@ -77,9 +77,6 @@ def add_parser(parser):
 
 
 def run_with(args, ctx=None):
-    if args.chi2:
-        # SURVEY.md 8(f) "next" row F7; refusing is louder than silently running Fisher
-        raise NotImplementedError("pairwise --chi2 is not built yet in the MI355X engine (Fisher exact only)")
     if args.filter_list is not None:
         with open(args.filter_list, "r") as fh:
             filter_list = set(line.rstrip() for line in fh)
@@ -105,7 +102,15 @@ def run_with(args, ctx=None):
         row_ptr, col = exclusion_csr(events, clusters)
         if totaln and pairs:
             excl = ctx.ps(counts, row_ptr, col, want_excl=True, want_ps=False)
-            parray = ctx.fisher_pairs(counts, excl)
+            if args.chi2:
+                parray, n_bad = ctx.chi2_pairs(counts, excl)
+                if n_bad:
+                    # scipy.stats.chi2_contingency raises on the first such table and the reference
+                    # run dies with it (pairwise_fisher.py:167-179)
+                    raise ValueError("The internally computed table of expected frequencies has a zero element "
+                                     f"({n_bad} of {parray.size} sample-pair tables have an empty row or column)")
+            else:
+                parray = ctx.fisher_pairs(counts, excl)
             if args.multiple_test_correction == "all":
                 parray = ctx.bh(parray.ravel()).reshape(parray.shape)
             elif args.multiple_test_correction == "pairwise":

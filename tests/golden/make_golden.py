@@ -236,6 +236,31 @@ def main():
                           multiple_test_correction="none", filter_list=os.path.join(pdir, "filter.txt"),
                           output=os.path.join(pdir, "expected_none_filtered.tsv")))
 
+    # --chi2 needs every expected frequency > 0 (scipy raises otherwise and the reference run aborts):
+    # keep the junctions that have overlaps and make every count positive
+    kept = [r for r, j in enumerate(tuples) if clusters[j]]
+    with open(os.path.join(pdir, "in_inclusionCounts_pos.tsv"), "w") as fh:
+        fh.write("cluster\t" + "\t".join(f"p{i}" for i in range(6)) + "\n")
+        for r in kept:
+            fh.write(jstr(tuples[r]) + "\t" + "\t".join(f"{x + 1:.0f}" for x in counts[r]) + "\n")
+    for mode in ("none", "pairwise"):
+        quiet(PF.run_with, ns(inclusionSPLICEDICE=os.path.join(pdir, "in_inclusionCounts_pos.tsv"),
+                              clusters=os.path.join(pdir, "in_allClusters.tsv"), chi2=True,
+                              multiple_test_correction=mode, filter_list=None,
+                              output=os.path.join(pdir, f"expected_chi2_{mode}.tsv")))
+    try:
+        quiet(PF.run_with, ns(inclusionSPLICEDICE=os.path.join(pdir, "in_inclusionCounts.tsv"),
+                              clusters=os.path.join(pdir, "in_allClusters.tsv"), chi2=True,
+                              multiple_test_correction="none", filter_list=None,
+                              output=os.path.join(pdir, "_should_not_exist.tsv")))
+        outcome = "completed"
+    except ValueError as e:
+        outcome = "ValueError: " + str(e)[:80]
+    with open(os.path.join(pdir, "chi2_on_zero_rows.json"), "w") as fh:
+        json.dump({"outcome": outcome}, fh)
+    if os.path.exists(os.path.join(pdir, "_should_not_exist.tsv")):
+        os.remove(os.path.join(pdir, "_should_not_exist.tsv"))
+
     # ------------------------------------------------------------------ KATs (scipy call sites)
     kats = []
     edge = [(0, 0, 5, 7), (0, 5, 0, 7), (3, 4, 0, 0), (5, 0, 7, 0), (1, 1, 1, 1), (10, 10, 10, 10),

@@ -337,3 +337,16 @@ def test_device_pipeline_matches_host_calls(ctx):
     d_recv = ctx.empty(n, np.float64)
     ctx.allgather_dev(out["p"], d_recv)
     assert np.array_equal(d_recv.to_host(), got["p"])
+
+
+# ------------------------------------------------------------------------------ chi2 (pairwise --chi2)
+def test_chi2_pairs_vs_scipy(ctx):
+    incl = synth.make_counts(30, 9, 501, mean=25) + 1
+    excl = (synth.make_counts(30, 9, 502, mean=90) + 1).astype(np.int64)
+    p, n_bad = ctx.chi2_pairs(incl, excl)
+    assert n_bad == 0
+    np.testing.assert_allclose(p, O.chi2_pairs(incl, excl), rtol=P_RTOL_TIGHT, atol=0)
+    excl[4, :] = 0
+    incl[4, 2] = 0
+    p, n_bad = ctx.chi2_pairs(incl, excl)
+    assert n_bad == 36 and np.isnan(p[4]).all() and not np.isnan(np.delete(p, 4, axis=0)).any()

@@ -157,3 +157,41 @@ def test_bh_matches_scipy():
     p[:10] = p[10]
     np.testing.assert_allclose(O.bh_fdr(p), false_discovery_control(p, method="bh"), rtol=1e-12, atol=0)
     assert O.bh_fdr(np.zeros(0)).size == 0
+
+
+def test_chi2_restatement_vs_scipy_and_reference_output(golden_dir):
+    from scipy.stats import chi2_contingency
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        t = rng.integers(1, 400, size=4)
+        w = chi2_contingency(t.reshape(2, 2))[1]
+        q = O.chi2_yates_restated(*t)
+        assert abs(q - w) <= 1e-12 * max(w, 1e-300)
+    with pytest.raises(ValueError):
+        O.chi2_yates_restated(3, 4, 0, 0)
+    d = os.path.join(golden_dir, "pairwise")
+    events, counts = [], []
+    with open(os.path.join(d, "in_inclusionCounts_pos.tsv")) as fh:
+        fh.readline()
+        for line in fh:
+            row = line.rstrip().split("\t")
+            events.append(row[0])
+            counts.append([int(x) for x in row[1:]])
+    counts = np.array(counts)
+    clusters = {}
+    for line in open(os.path.join(d, "in_allClusters.tsv")):
+        parts = line.rstrip().split()
+        clusters[parts[0]] = parts[1].split(",") if len(parts) == 2 else []
+    idx = {e: i for i, e in enumerate(events)}
+    row_ptr = np.zeros(len(events) + 1, np.int64)
+    col = []
+    for n, e in enumerate(events):
+        col.extend(idx[o] for o in clusters[e] if o in idx)
+        row_ptr[n + 1] = len(col)
+    excl = O.pairwise_exclusions(counts, row_ptr, np.array(col, np.int32))
+    p = O.chi2_pairs(counts, excl, use_scipy=False)
+    with open(os.path.join(d, "expected_chi2_none.tsv")) as fh:
+        fh.readline()
+        for line, row in zip(fh, p):
+            want = np.array([float(x) for x in line.rstrip("\n").split("\t")[1:]])
+            np.testing.assert_allclose(row, want, rtol=1e-12, atol=0)
