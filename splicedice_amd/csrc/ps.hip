@@ -58,10 +58,6 @@ __device__ __forceinline__ float ps_value64(unsigned incl, unsigned long long ex
     const double t = a + (double)excl;
     return (float)(a / t);
 }
-__device__ __forceinline__ float ps_value32(unsigned incl, unsigned excl) {
-    // valid when incl + excl < 2^24 (see header): one correctly rounded float32 division
-    return (float)incl / (float)(incl + excl);
-}
 
 __device__ __forceinline__ unsigned vmax(const int4& v) {
     return max(max((unsigned)v.x, (unsigned)v.y), max((unsigned)v.z, (unsigned)v.w));
@@ -93,78 +89,96 @@ template <int VEC, typename ACC> __device__ __forceinline__ void store_excl(int6
     }
 }
 
-// Gather + divide one (row, vector) item.  FAST: 32-bit sums + float32 division; returns false
-// (nothing stored) if a neighbour read through the global fallback breaks the tile's bound.
-template <int VEC, bool FAST, bool WEXCL, bool WPS>
-__device__ __forceinline__ bool ps_item(const PsArgs& a, const char* tileB, const int* colL, bool col_in_lds,
-                                        int64_t kbase, int k0, int k1, int slo, int wrows, int ldw, int c0, int cvec,
-                                        int own_row, int64_t out_index, unsigned thr, int zero_off) {
+__device__ __forceinline__ float div_small_ints(float a, float t) {
+    // a / t for exact integers 0 <= a <= t < 2^24: the Newton / residual steps of the IEEE
+    // float32 division sequence without v_div_scale / v_div_fixup (no scaling is ever needed in
+    // this range), hence the same correctly rounded quotient in 8 instead of 13 instructions.
+    // t == 0 (then a == 0): rcp = inf, e = NaN -> NaN, as 0/0.
+    float r = __builtin_amdgcn_rcpf(t);
+    const float e = __builtin_fmaf(-t, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float rem = __builtin_fmaf(-t, q, a);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-t, q, a);
+    return __builtin_fmaf(rem, r, q);
+}
+
+// Fast item: every neighbour offset comes from the LDS stage and lies inside the staged window,
+// the tile's bound keeps incl + excl < 2^24 -> 32-bit sums, float32 quotient.  Returns false
+// (nothing stored) as soon as a neighbour is outside the window; the caller then runs ps_item_slow.
+template <int VEC, bool WEXCL, bool WPS>
+__device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB, const int* colL, int k0, int k1,
+                                             int cbytes, int own_off, int64_t out_index, int zero_off) {
     typedef typename Vt<VEC>::I VI;
-    typedef typename std::conditional<FAST, unsigned, unsigned long long>::type ACC;
-    ACC acc[VEC];
+    unsigned acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0;
-    bool ok = true;
-    const int cbytes = cvec * 4;
-    int k = k0;
-    if (col_in_lds) {
-        // batches of GB neighbours: all offset reads, then all row reads, then the adds -- two LDS
-        // round trips per batch instead of two per neighbour; short batches are padded with the
-        // all-zero row kept behind the window
-        constexpr int GB = 4;
-        for (; k < k1; k += GB) {
-            int off[GB];
+    // batches of GB neighbours: all offset reads, then all row reads, then the adds -- two LDS
+    // round trips per batch instead of two per neighbour; short batches are padded with the
+    // all-zero row kept behind the window
+    constexpr int GB = 4;
+    for (int k = k0; k < k1; k += GB) {
+        int off[GB];
 #pragma unroll
-            for (int u = 0; u < GB; ++u) off[u] = (k + u < k1) ? colL[k + u] : zero_off;
-            int mn = off[0];
+        for (int u = 0; u < GB; ++u) off[u] = (k + u < k1) ? colL[k + u] : zero_off;
+        int mn = off[0];
 #pragma unroll
-            for (int u = 1; u < GB; ++u) mn = min(mn, off[u]);
-            if (mn >= 0) {
-                VI v[GB];
+        for (int u = 1; u < GB; ++u) mn = min(mn, off[u]);
+        if (mn < 0) return false;
+        VI v[GB];
 #pragma unroll
-                for (int u = 0; u < GB; ++u) v[u] = *reinterpret_cast<const VI*>(tileB + off[u] + cbytes);
+        for (int u = 0; u < GB; ++u) v[u] = *reinterpret_cast<const VI*>(tileB + off[u] + cbytes);
 #pragma unroll
-                for (int u = 0; u < GB; ++u) acc_add(acc, v[u]);
-            } else {
-                // a neighbour outside the staged window: global-memory path
-#pragma unroll
-                for (int u = 0; u < GB; ++u) {
-                    VI v;
-                    if (off[u] >= 0) {
-                        v = *reinterpret_cast<const VI*>(tileB + off[u] + cbytes);
-                    } else {
-                        const int j = -1 - off[u];
-                        v = *reinterpret_cast<const VI*>(a.counts + (int64_t)j * a.s + c0 + cvec);
-                        if (FAST && vmax(v) > thr) ok = false;
-                    }
-                    acc_add(acc, v);
-                }
-            }
-        }
+        for (int u = 0; u < GB; ++u) acc_add(acc, v[u]);
     }
-    for (; k < k1; ++k) {      // neighbour list too long for the LDS stage: indices from global memory
-        const int j = a.col[kbase + k];
-        const unsigned rel = (unsigned)(j - slo);
-        VI v;
-        if (rel < (unsigned)wrows) {
-            v = *reinterpret_cast<const VI*>(tileB + rel * (unsigned)ldw * 4u + cbytes);
-        } else {
-            v = *reinterpret_cast<const VI*>(a.counts + (int64_t)j * a.s + c0 + cvec);
-            if (FAST && vmax(v) > thr) ok = false;
-        }
-        acc_add(acc, v);
-    }
-    if (FAST && !ok) return false;
-    const VI own = *reinterpret_cast<const VI*>(tileB + own_row * ldw * 4 + cbytes);
+    const VI own = *reinterpret_cast<const VI*>(tileB + own_off + cbytes);
     if (WPS) {
         float o[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q)
-            o[q] = FAST ? ps_value32(comp(own, q), (unsigned)acc[q]) : ps_value64(comp(own, q), (unsigned long long)acc[q]);
+        for (int q = 0; q < VEC; ++q) {
+            const unsigned in = comp(own, q);
+            o[q] = div_small_ints((float)in, (float)(in + acc[q]));
+        }
         if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
     }
-    if (WEXCL) store_excl<VEC, ACC>(a.excl + out_index, acc);
+    if (WEXCL) store_excl<VEC, unsigned>(a.excl + out_index, acc);
     return true;
+}
+
+// General item: neighbours from the LDS window or from global memory, indices from the LDS stage
+// or from global memory, 64-bit sums, float64 division.  Exact for any valid CSR and any counts.
+template <int VEC, bool WEXCL, bool WPS>
+__device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB, const int* colL, bool col_in_lds,
+                                             int64_t kbase, int k0, int k1, int slo, int wrows, int ldw, int c0, int cvec,
+                                             int own_off, int64_t out_index) {
+    typedef typename Vt<VEC>::I VI;
+    unsigned long long acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0;
+    const int cbytes = cvec * 4;
+    for (int k = k0; k < k1; ++k) {
+        int off;
+        if (col_in_lds) {
+            off = colL[k];
+        } else {
+            const int j = a.col[kbase + k];
+            const unsigned rel = (unsigned)(j - slo);
+            off = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
+        }
+        VI v;
+        if (off >= 0) v = *reinterpret_cast<const VI*>(tileB + off + cbytes);
+        else v = *reinterpret_cast<const VI*>(a.counts + (int64_t)(-1 - off) * a.s + c0 + cvec);
+        acc_add(acc, v);
+    }
+    const VI own = *reinterpret_cast<const VI*>(tileB + own_off + cbytes);
+    if (WPS) {
+        float o[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) o[q] = ps_value64(comp(own, q), acc[q]);
+        if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
+    }
+    if (WEXCL) store_excl<VEC, unsigned long long>(a.excl + out_index, acc);
 }
 
 template <int VEC, bool WEXCL, bool WPS>
@@ -257,7 +271,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     __syncthreads();
     const unsigned tile_cmax = red[0], tile_dmax = red[1];
     const unsigned thr = 0xFFFFFFu / (tile_dmax + 1u);   // per-count bound keeping incl+excl < 2^24
-    const bool fast = tile_cmax <= thr;                   // block-uniform
+    const bool fast = tile_cmax <= thr && col_in_lds;     // block-uniform
 
     // ---- per (row, vector) item: gather neighbours from LDS, divide, store
     {
@@ -269,13 +283,13 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
         for (int it = tid; it < items; it += T) {
             const int k0 = rpL[ri], k1 = (a.ablate & 1) ? k0 : rpL[ri + 1];
             const int64_t o = (r0 + ri) * a.s + c0 + c * VEC;
+            const int own_off = (own_base + ri) * ldw * 4;
             bool done = false;
             if (fast)
-                done = ps_item<VEC, true, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0,
-                                                      c * VEC, own_base + ri, o, thr, zero_off);
+                done = ps_item_fast<VEC, WEXCL, WPS>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
             if (!done)
-                ps_item<VEC, false, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
-                                                own_base + ri, o, thr, zero_off);
+                ps_item_slow<VEC, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
+                                              own_off, o);
             c += dc; ri += dr;
             if (c >= V) { c -= V; ri += 1; }
         }
@@ -367,6 +381,9 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
         if (d_col != nullptr && d_col == ctx->d_col && ctx->cluster_reach > 0 && ctx->cluster_reach < H)
             H = ctx->cluster_reach;
     }
+    // (a software-pipelined persistent variant -- one workgroup per CU, two LDS buffers, next tile's
+    //  loads in flight during the gather -- was built and measured 30 % slower: the kernel is VALU-issue
+    //  bound, and halving the resident waves costs more than hiding the load latency gains)
     int64_t R = ctx->param("ps.tile_rows", 0);
     if (R <= 0) R = (L - (2 * H + 1) * cw) / (cw + 17);
     if (R > 2 * threads) R = 2 * threads;   // the kernel keeps two row pointers per thread in registers
@@ -379,6 +396,8 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     if (R < 1) R = 1;
     while (R > 1 && (R + 2 * H + 1) * cw + 17 * R > L) R -= 1;
     SD_ARG((R + 2 * H + 1) * cw + 17 * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
+    // (trimming R so that R * V is a multiple of the block size was measured: slower -- the per-tile
+    //  fixed cost outweighs the idle lanes of the last pass over the items)
     if (R > n) { R = n; }
 
     PsArgs a;

@@ -350,3 +350,34 @@ def test_chi2_pairs_vs_scipy(ctx):
     incl[4, 2] = 0
     p, n_bad = ctx.chi2_pairs(incl, excl)
     assert n_bad == 36 and np.isnan(p[4]).all() and not np.isnan(np.delete(p, 4, axis=0)).any()
+
+
+def test_ps_fast_path_division_is_exact(ctx):
+    """The float32 fast path (no v_div_scale / v_div_fixup) must equal float32(float64 quotient)
+    over its whole domain: numerators and denominators up to 2^24, incl. 0/0 and 0/x."""
+    rng = np.random.default_rng(11)
+    n, s = 4096, 64
+    # ring of junctions: row r has neighbours r-1 and r+1 -> degree 2, bound = (2^24-1)/3
+    row_ptr = np.arange(0, 2 * n + 1, 2, dtype=np.int64)
+    col = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], axis=1).ravel().astype(np.int32)
+    top = (1 << 24) // 3 - 1
+    counts = rng.integers(0, top, size=(n, s), dtype=np.int32)
+    counts[rng.random((n, s)) < 0.3] = 0
+    counts[:64] = rng.integers(0, 4, size=(64, s))            # small integers: many exact ties and 0/0
+    counts[100:164, :] = top
+    want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+    assert np.array_equal(excl, want_excl)
+    assert np.array_equal(ps, want_ps, equal_nan=True)
+    # every quotient a/(a+b) with small a, b, through the same path
+    a, b = np.meshgrid(np.arange(0, 257), np.arange(0, 257))
+    c2 = np.zeros((2 * a.size, 4), np.int32)
+    c2[0::2, :] = a.ravel()[:, None]
+    c2[1::2, :] = b.ravel()[:, None]
+    rp = np.zeros(2 * a.size + 1, np.int64)
+    rp[1:] = np.cumsum(np.tile([1, 0], a.size))
+    cl = np.arange(1, 2 * a.size, 2, dtype=np.int32)           # row 2i has the single neighbour 2i+1
+    ps2 = ctx.ps(c2, rp, cl)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        w = (a.ravel().astype(np.float64) / (a.ravel() + b.ravel()).astype(np.float64)).astype(np.float32)
+    assert np.array_equal(ps2[0::2, 0], w, equal_nan=True)
