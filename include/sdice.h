@@ -152,6 +152,23 @@ int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double* d_q);
  * (pairwise_fisher.py:187-191) */
 int sdice_bh_columns(sdice_ctx* ctx, int64_t n, int64_t cols, double* p_inout);
 
+/* ---- host-side table text I/O (no device, no context): multithreaded, byte-compatible with the
+ *      reference's writers  f'{x:.3f}' (SPLICEDICE.py:353, counts_to_ps.py:69), f'{x:.0f}'
+ *      (SPLICEDICE.py:340), str(numpy.float64) (pairwise_fisher.py:200)  and with its readers
+ *      (text -> float64 -> dtype: compareSampleSets.py:202, pairwise_fisher.py:60, counts_to_ps.py:50).
+ *  Tables are  header-line '\n'  then one line per row:  name '\t' v '\t' v ... '\n'.
+ *  names: concatenated row names, name_off[n+1] byte offsets into it.
+ *  dtype 0 float32, 1 float64, 2 int32;  mode 0 '%.3f', 1 '%.0f', 2 numpy str() shortest repr. */
+int sdice_write_table(const char* path, const char* header /* incl. '\n' */, int64_t n, int32_t s,
+                      const char* names, const int64_t* name_off, const void* data, int dtype, int mode,
+                      int threads /* 0 = all cores */);
+typedef struct sdice_table sdice_table;
+int sdice_table_open(const char* path, sdice_table** out, int64_t* n, int32_t* s, int64_t* names_bytes,
+                     int64_t* header_bytes);
+int sdice_table_read(sdice_table* t, char* header, char* names, int64_t* name_off, void* data,
+                     int dtype /* 0 float32, 1 float64 */, int threads);
+int sdice_table_close(sdice_table* t);
+
 /* ---- multi-GPU (new; the reference is single-process): one context per rank,
  *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque
  *      bytes created on rank 0 and distributed by the caller (any channel). */

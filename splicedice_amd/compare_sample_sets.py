@@ -29,16 +29,9 @@ def column_indices(group, cols):
 
 def read_ps_table(path):
     """`_allPS.tsv` -> (row names array, column names array, float32 matrix), :193-204."""
-    rows, data = [], []
-    with open(path) as tsv:
-        headers = tsv.readline().strip().split("\t")[1:]
-        for line in tsv:
-            row = line.strip().split("\t")
-            rows.append(row[0])
-            data.append(row[1:])
-    matrix = np.array(data, dtype="float32")
-    if matrix.ndim != 2:
-        matrix = matrix.reshape(len(rows), len(headers))
+    from . import textio
+    header, rows, matrix = textio.read_table_numeric(path, np.float32)     # text -> float64 -> float32, as numpy
+    headers = header.strip().split("\t")[1:]
     return np.array(rows), np.array(headers), matrix
 
 

@@ -44,12 +44,11 @@ def determine_clusters(counts_file, ctx):
 
 def get_counts(count_file):
     """header line + name -> row index, int32 matrix (counts_to_ps.py:43-51)."""
-    header, names, rows = textio.read_table(count_file)
+    header, names, data = textio.read_table_numeric(count_file, np.float64)
     index = {}
     for i, name in enumerate(names):
         index[name] = i                           # a repeated name keeps its last row, as a dict would
-    counts = textio.counts_to_int32(np.array(rows, dtype=float), count_file) if rows else np.zeros((0, 0), np.int32)
-    return header, index, counts
+    return header, index, textio.counts_to_int32(data, count_file)
 
 
 def write_ps_values(clusters, header, index, counts, output_prefix, ctx):
@@ -81,10 +80,7 @@ def write_ps_values(clusters, header, index, counts, output_prefix, ctx):
     own = table[:len(j_list)].astype(np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
         ps = own / (own + excl[:len(j_list)].astype(np.float64))
-    with open(f"{output_prefix}_allPS.tsv", "w") as psfile:
-        psfile.write(header)
-        for name, row in zip(j_list, ps):
-            psfile.write(name + "\t" + "\t".join(f"{x:0.3f}" for x in row) + "\n")
+    textio.write_table(f"{output_prefix}_allPS.tsv", header, j_list, ps, ".3f")      # f"{x:0.3f}" on float64
 
 
 def write_clusters(clusters, output_prefix):

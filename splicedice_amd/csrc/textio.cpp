@@ -1,0 +1,343 @@
+// Host-side table I/O behind the same C ABI (text I/O on both sides of the
+// hot path).  Multithreaded formatter / parser for the reference's inter-stage tables
+//     cluster<TAB>s0<TAB>s1...            (header line)
+//     name<TAB>v<TAB>v...                 (one line per junction)
+// byte-compatible with the reference's writers:
+//   f'{x:.3f}' on float32 / float64   (SPLICEDICE.py:353, counts_to_ps.py:69)
+//   f'{x:.0f}' on float32 counts      (SPLICEDICE.py:340)
+//   str(numpy.float64)                (pairwise_fisher.py:200: shortest round-trip repr,
+//                                      positional for 1e-4 <= |x| < 1e16, else d.ddde+XX)
+// and with its readers (numpy string -> float64 -> dtype; compareSampleSets.py:202,
+// pairwise_fisher.py:60, counts_to_ps.py:50).  No device code here.
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include "sdice.h"
+
+void sdice_set_error(const char* fmt, ...);
+
+namespace {
+
+inline void put_fixed3(std::string& out, double x) {
+    // '%.3f' of x: exact fast path for 0 <= x < 1000 via k = x*1000 when that product is exact
+    if (std::isnan(x)) { out += "nan"; return; }
+    if (x >= 0.0 && x < 1000.0) {
+        const float xf = (float)x;
+        if ((double)xf == x) {                          // float32 input: x*1000 is exact in double
+            const double k = std::nearbyint(x * 1000.0);   // default rounding mode: half to even, as printf
+            const uint32_t v = (uint32_t)k;
+            char buf[16];
+            int n = 0;
+            uint32_t ip = v / 1000, fp = v % 1000;
+            char tmp[8];
+            int t = 0;
+            do { tmp[t++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+            if (std::signbit(x)) buf[n++] = '-';
+            while (t) buf[n++] = tmp[--t];
+            buf[n++] = '.';
+            buf[n++] = (char)('0' + fp / 100);
+            buf[n++] = (char)('0' + (fp / 10) % 10);
+            buf[n++] = (char)('0' + fp % 10);
+            out.append(buf, n);
+            return;
+        }
+    }
+    char buf[512];
+    const int n = snprintf(buf, sizeof(buf), "%.3f", x);
+    out.append(buf, n);
+}
+
+inline void put_fixed0(std::string& out, double x) {
+    if (x >= 0.0 && x < 4294967296.0 && x == std::floor(x)) {
+        char buf[16];
+        auto r = std::to_chars(buf, buf + sizeof(buf), (uint32_t)x);
+        out.append(buf, r.ptr - buf);
+        return;
+    }
+    if (std::isnan(x)) { out += "nan"; return; }
+    char buf[512];
+    const int n = snprintf(buf, sizeof(buf), "%.0f", x);
+    out.append(buf, n);
+}
+
+template <typename T>
+inline void put_repr(std::string& out, T x) {
+    // numpy str(float32/float64) == Python repr rule on the shortest round-trip digits
+    if (std::isnan(x)) { out += "nan"; return; }
+    if (std::isinf(x)) { out += x < 0 ? "-inf" : "inf"; return; }
+    if (x == 0) { out += std::signbit(x) ? "-0.0" : "0.0"; return; }
+    char sci[64];
+    auto r = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest
+    *r.ptr = 0;
+    const char* e = strchr(sci, 'e');
+    const int exp10 = atoi(e + 1);
+    // digits without sign / point
+    char digits[40];
+    int nd = 0;
+    const char* p = sci;
+    const bool neg = *p == '-';
+    if (neg) ++p;
+    for (; p < e; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    if (neg) out += '-';
+    if (exp10 >= -4 && exp10 < 16) {
+        if (exp10 >= 0) {
+            for (int i = 0; i <= exp10; ++i) out += i < nd ? digits[i] : '0';
+            out += '.';
+            if (nd > exp10 + 1) out.append(digits + exp10 + 1, nd - exp10 - 1);
+            else out += '0';
+        } else {
+            out += "0.";
+            for (int i = 0; i < -exp10 - 1; ++i) out += '0';
+            out.append(digits, nd);
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) { out += '.'; out.append(digits + 1, nd - 1); }
+        out += 'e';
+        out += exp10 < 0 ? '-' : '+';
+        const int a = exp10 < 0 ? -exp10 : exp10;
+        if (a < 10) out += '0';
+        char eb[8];
+        auto r2 = std::to_chars(eb, eb + sizeof(eb), a);
+        out.append(eb, r2.ptr - eb);
+    }
+}
+
+template <typename F>
+void parallel_rows(int64_t n, int threads, F&& fn) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (n < 4096) threads = 1;
+    if (threads == 1) { fn(0, 0, n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const int64_t a = n * t / threads, b = n * (t + 1) / threads;
+        pool.emplace_back([=, &fn] { fn(t, a, b); });
+    }
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+// mode: 0 = '%.3f', 1 = '%.0f', 2 = numpy str() shortest repr
+// dtype: 0 = float32, 1 = float64, 2 = int32 (mode 1 only)
+extern "C" int sdice_write_table(const char* path, const char* header, int64_t n, int32_t s, const char* names,
+                                 const int64_t* name_off, const void* data, int dtype, int mode, int threads) {
+    if (!path || !header || n < 0 || s < 0 || (n > 0 && (!names || !name_off || (!data && s > 0)))) {
+        sdice_set_error("sdice_write_table: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    if (dtype < 0 || dtype > 2 || mode < 0 || mode > 2 || (dtype == 2 && mode != 1)) {
+        sdice_set_error("sdice_write_table: unsupported dtype/mode combination");
+        return SDICE_ERR_ARG;
+    }
+    FILE* fh = fopen(path, "wb");
+    if (!fh) {
+        sdice_set_error("sdice_write_table: cannot open %s", path);
+        return SDICE_ERR_ARG;
+    }
+    fwrite(header, 1, strlen(header), fh);
+    // rows are formatted in blocks so that memory stays bounded and the writes stay ordered
+    const int64_t block = 1 << 16;
+    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    std::vector<std::string> bufs;
+    for (int64_t r0 = 0; r0 < n; r0 += block) {
+        const int64_t nb = std::min(block, n - r0);
+        int used = nb < 4096 ? 1 : std::min(nthreads, 64);
+        if (used < 1) used = 1;
+        bufs.assign(used, std::string());
+        parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
+            std::string& out = bufs[t];
+            out.reserve((size_t)(b - a) * ((size_t)s * 8 + 32));
+            for (int64_t r = r0 + a; r < r0 + b; ++r) {
+                out.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+                for (int32_t c = 0; c < s; ++c) {
+                    out += '\t';
+                    const size_t i = (size_t)r * (size_t)s + (size_t)c;
+                    if (dtype == 2) {
+                        char b2[16];
+                        auto rr = std::to_chars(b2, b2 + sizeof(b2), ((const int32_t*)data)[i]);
+                        out.append(b2, rr.ptr - b2);
+                    } else if (dtype == 0) {
+                        const float v = ((const float*)data)[i];
+                        if (mode == 0) put_fixed3(out, (double)v);
+                        else if (mode == 1) put_fixed0(out, (double)v);
+                        else put_repr<float>(out, v);
+                    } else {
+                        const double v = ((const double*)data)[i];
+                        if (mode == 0) put_fixed3(out, v);
+                        else if (mode == 1) put_fixed0(out, v);
+                        else put_repr<double>(out, v);
+                    }
+                }
+                out += '\n';
+            }
+        });
+        for (auto& b : bufs)
+            if (!b.empty() && fwrite(b.data(), 1, b.size(), fh) != b.size()) {
+                fclose(fh);
+                sdice_set_error("sdice_write_table: short write to %s", path);
+                return SDICE_ERR_ARG;
+            }
+    }
+    if (fclose(fh) != 0) {
+        sdice_set_error("sdice_write_table: close failed for %s", path);
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ reader
+struct sdice_table {
+    int fd = -1;
+    const char* base = nullptr;
+    size_t size = 0;
+    size_t body = 0;                  // offset of the first data line
+    std::vector<size_t> line_start;   // n + 1 entries (last = end of data)
+    int64_t n = 0;
+    int32_t s = 0;
+    int64_t names_bytes = 0;
+    int rstrip_mode = 0;
+};
+
+extern "C" int sdice_table_close(sdice_table* t) {
+    if (!t) return SDICE_OK;
+    if (t->base && t->size) munmap((void*)t->base, t->size);
+    if (t->fd >= 0) close(t->fd);
+    delete t;
+    return SDICE_OK;
+}
+
+// Opens a table and indexes its lines.  n = data lines, s = tab-separated value columns of the
+// header (= header fields - 1), names_bytes = total length of the first field of every line.
+extern "C" int sdice_table_open(const char* path, sdice_table** out, int64_t* n, int32_t* s, int64_t* names_bytes,
+                                int64_t* header_bytes) {
+    if (!path || !out) { sdice_set_error("sdice_table_open: bad arguments"); return SDICE_ERR_ARG; }
+    *out = nullptr;
+    sdice_table* t = new sdice_table();
+    t->fd = open(path, O_RDONLY);
+    struct stat st;
+    if (t->fd < 0 || fstat(t->fd, &st) != 0) {
+        sdice_set_error("sdice_table_open: cannot open %s", path);
+        sdice_table_close(t);
+        return SDICE_ERR_ARG;
+    }
+    t->size = (size_t)st.st_size;
+    if (t->size) {
+        void* m = mmap(nullptr, t->size, PROT_READ, MAP_PRIVATE, t->fd, 0);
+        if (m == MAP_FAILED) {
+            sdice_set_error("sdice_table_open: mmap failed for %s", path);
+            t->size = 0;
+            sdice_table_close(t);
+            return SDICE_ERR_ARG;
+        }
+        t->base = (const char*)m;
+    }
+    const char* p = t->base;
+    const char* end = p + t->size;
+    const char* nl = t->size ? (const char*)memchr(p, '\n', t->size) : nullptr;
+    const char* hend = nl ? nl : end;
+    int fields = t->size ? 1 : 0;
+    for (const char* q = p; q < hend; ++q) fields += (*q == '\t');
+    t->s = fields > 0 ? fields - 1 : 0;
+    t->body = nl ? (size_t)(nl + 1 - p) : t->size;
+    // line index (single pass; memchr is fast enough to not need threads)
+    size_t pos = t->body;
+    while (pos < t->size) {
+        t->line_start.push_back(pos);
+        const char* e = (const char*)memchr(p + pos, '\n', t->size - pos);
+        pos = e ? (size_t)(e + 1 - p) : t->size;
+    }
+    t->line_start.push_back(t->size);
+    t->n = (int64_t)t->line_start.size() - 1;
+    int64_t nb = 0;
+    for (int64_t i = 0; i < t->n; ++i) {
+        const char* a = p + t->line_start[i];
+        const char* b = p + t->line_start[i + 1];
+        const char* tab = (const char*)memchr(a, '\t', (size_t)(b - a));
+        const char* stop = tab ? tab : b;
+        while (stop > a && (stop[-1] == '\n' || stop[-1] == '\r')) --stop;
+        nb += stop - a;
+    }
+    t->names_bytes = nb;
+    if (n) *n = t->n;
+    if (s) *s = t->s;
+    if (names_bytes) *names_bytes = nb;
+    if (header_bytes) *header_bytes = (int64_t)t->body;
+    *out = t;
+    return SDICE_OK;
+}
+
+// Fills header (header_bytes incl. newline, not NUL terminated), names blob + offsets[n+1] and
+// data[n, s] (dtype 0 float32, 1 float64; numpy semantics: text -> float64 -> dtype).
+// A line with a different number of fields than the header is an error, as numpy would raise.
+extern "C" int sdice_table_read(sdice_table* t, char* header, char* names, int64_t* name_off, void* data, int dtype,
+                                int threads) {
+    if (!t || (t->n > 0 && (!names || !name_off || (!data && t->s > 0))) || dtype < 0 || dtype > 1) {
+        sdice_set_error("sdice_table_read: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    if (header && t->body) memcpy(header, t->base, t->body);
+    // name offsets first (serial prefix), then parallel parse
+    int64_t off = 0;
+    std::vector<const char*> name_end((size_t)t->n);
+    for (int64_t i = 0; i < t->n; ++i) {
+        const char* a = t->base + t->line_start[i];
+        const char* b = t->base + t->line_start[i + 1];
+        const char* tab = (const char*)memchr(a, '\t', (size_t)(b - a));
+        const char* stop = tab ? tab : b;
+        while (stop > a && (stop[-1] == '\n' || stop[-1] == '\r')) --stop;
+        name_off[i] = off;
+        memcpy(names + off, a, (size_t)(stop - a));
+        off += stop - a;
+        name_end[(size_t)i] = tab ? tab : stop;
+    }
+    if (t->n >= 0 && name_off) name_off[t->n] = off;
+    std::vector<int64_t> bad((size_t)64, -1);
+    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (nthreads > 64) nthreads = 64;
+    parallel_rows(t->n, nthreads, [&](int tix, int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            const char* p = name_end[(size_t)i];
+            const char* end = t->base + t->line_start[i + 1];
+            while (end > p && (end[-1] == '\n' || end[-1] == '\r' || end[-1] == ' ')) --end;   // line.rstrip()
+            int32_t c = 0;
+            while (p < end && c < t->s) {
+                if (*p != '\t') { bad[tix] = i; break; }
+                ++p;
+                const char* q = (const char*)memchr(p, '\t', (size_t)(end - p));
+                const char* fe = q ? q : end;
+                double v = 0.0;
+                const char* fs = p;
+                while (fs < fe && *fs == ' ') ++fs;
+                if (fs < fe && *fs == '+') ++fs;     // from_chars rejects a leading '+', float() accepts it
+                auto r = std::from_chars(fs, fe, v);
+                if (r.ec != std::errc() || r.ptr != fe) { bad[tix] = i; break; }
+                const size_t idx = (size_t)i * (size_t)t->s + (size_t)c;
+                if (dtype == 0) ((float*)data)[idx] = (float)v;
+                else ((double*)data)[idx] = v;
+                ++c;
+                p = fe;
+            }
+            if (bad[tix] == i) break;
+            if (c != t->s || p != end) { bad[tix] = i; break; }
+        }
+    });
+    for (auto b : bad)
+        if (b >= 0) {
+            sdice_set_error("sdice_table_read: line %lld is not %d numeric tab-separated fields", (long long)(b + 2),
+                            (int)t->s);
+            return SDICE_ERR_ARG;
+        }
+    return SDICE_OK;
+}

@@ -32,15 +32,12 @@ def get_clusters(filename):
 
 def get_event_counts(filename, filter_list=None):
     """samples, events, int32 counts; `-f` keeps only listed rows (pairwise_fisher.py:46-61)."""
-    events, counts = [], []
-    with open(filename) as tsv:
-        samples = tsv.readline().rstrip().split("\t")[1:]
-        for line in tsv:
-            row = line.rstrip().split("\t")
-            if filter_list is None or row[0] in filter_list:
-                events.append(row[0])
-                counts.append(row[1:])
-    mat = np.array(counts, dtype=float).reshape(len(events), -1) if events else np.zeros((0, len(samples)))
+    header, events, mat = textio.read_table_numeric(filename, np.float64)
+    samples = header.rstrip().split("\t")[1:]
+    if filter_list is not None:
+        keep = [i for i, e in enumerate(events) if e in filter_list]
+        events = [events[i] for i in keep]
+        mat = mat[keep] if keep else np.zeros((0, len(samples)))
     return samples, events, textio.counts_to_int32(mat, filename)
 
 
@@ -121,10 +118,9 @@ def run_with(args, ctx=None):
         if own_ctx:
             ctx.close()
 
-    with open(args.output, "w") as outfile:
-        outfile.write("clusterID\t" + "\t".join(columns) + "\n")
-        for name, pvalues in zip(events, parray):
-            outfile.write(name + "\t" + "\t".join(str(p) for p in pvalues) + "\n")
+    # str(numpy.float64) per cell (pairwise_fisher.py:195-200) through the library's formatter
+    textio.write_table(args.output, "clusterID\t" + "\t".join(columns) + "\n", events,
+                       np.asarray(parray, dtype=np.float64).reshape(len(events), len(pairs)), "repr")
 
 
 if __name__ == "__main__":

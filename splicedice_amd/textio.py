@@ -54,6 +54,60 @@ def counts_to_int32(values, what):
     return arr.astype(np.int32)
 
 
+_DTYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2}
+_MODE_CODE = {".3f": 0, ".0f": 1, "repr": 2}
+
+
+def write_table(path, header, names, data, mode, threads=0):
+    """Write `header` + one 'name<TAB>values' line per row through the library's multithreaded
+    formatter (sdice_write_table).  mode: '.3f' | '.0f' | 'repr' (numpy str of float32/float64).
+    Byte-identical to the reference's per-element f-string writers."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    data = np.ascontiguousarray(data)
+    if data.dtype not in _DTYPE_CODE:
+        raise TypeError(f"write_table: unsupported dtype {data.dtype}")
+    n = len(names)
+    s = data.shape[1] if data.ndim == 2 else 0
+    assert data.shape[0] == n
+    blobs = [str(nm).encode() for nm in names]
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum([len(b) for b in blobs], out=off[1:])
+    blob = b"".join(blobs)
+    rc = lib.sdice_write_table(str(path).encode(), header.encode(), n, s, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
+                               data.ctypes.data_as(C.c_void_p), _DTYPE_CODE[data.dtype], _MODE_CODE[mode], int(threads))
+    _ffi.check(rc, "sdice_write_table")
+
+
+def read_table_numeric(path, dtype=np.float32, threads=0):
+    """-> (header_line, names list, data[n, s]) through the library's mmap + multithreaded parser
+    (numpy semantics: text -> float64 -> dtype)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    dtype = np.dtype(dtype)
+    code = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}[dtype]
+    h = C.c_void_p()
+    n, s, nb, hb = C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64()
+    _ffi.check(lib.sdice_table_open(str(path).encode(), C.byref(h), C.byref(n), C.byref(s), C.byref(nb), C.byref(hb)),
+               "sdice_table_open")
+    try:
+        header = C.create_string_buffer(max(1, hb.value))
+        names = C.create_string_buffer(max(1, nb.value))
+        off = np.zeros(n.value + 1, dtype=np.int64)
+        data = np.empty((n.value, s.value), dtype=dtype)
+        _ffi.check(lib.sdice_table_read(h, header, names, off.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p),
+                                        code, int(threads)), "sdice_table_read")
+    finally:
+        lib.sdice_table_close(h)
+    text = names.raw[:nb.value].decode()
+    name_list = [text[off[i]:off[i + 1]] for i in range(n.value)] if text.isascii() else \
+        [names.raw[off[i]:off[i + 1]].decode() for i in range(n.value)]
+    return header.raw[:hb.value].decode(), name_list, data
+
+
 def read_table(path, strip_lines=False):
     """'cluster<TAB>s0<TAB>s1...' table -> (header_line, names list, rows list of str lists)."""
     names, rows = [], []

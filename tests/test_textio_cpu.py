@@ -1,0 +1,109 @@
+"""CPU: the library's table formatter / parser is byte-compatible with the reference's Python
+text I/O (f'{x:.3f}', f'{x:.0f}', str(numpy scalar); numpy string -> float parsing)."""
+import os
+
+import numpy as np
+import pytest
+
+from splicedice_amd import textio
+
+
+def _roundtrip(tmp_path, data, mode, fmt):
+    n = data.shape[0]
+    names = [f"chr{1 + i % 7}:{i}-{i + 9}:{'+-'[i % 2]}" for i in range(n)]
+    path = str(tmp_path / "t.tsv")
+    header = "cluster\t" + "\t".join(f"s{c}" for c in range(data.shape[1])) + "\n"
+    textio.write_table(path, header, names, data, mode)
+    with open(path) as fh:
+        got = fh.read().split("\n")
+    assert got[0] + "\n" == header and got[-1] == ""
+    for i in range(n):
+        want = names[i] + "\t" + "\t".join(fmt(x) for x in data[i])
+        assert got[1 + i] == want, (i, got[1 + i][:80], want[:80])
+    return path, header, names
+
+
+def test_write_fixed3_float32(tmp_path):
+    rng = np.random.default_rng(0)
+    k = np.arange(0, 1001) / 1000.0
+    vals = np.concatenate([k, k + 0.0005, rng.random(6000), rng.random(500) * 1e4, -rng.random(200),
+                           [np.nan, -0.0, 0.0, 1.0, 0.9995, 0.99949, 123456.7, np.inf, -np.inf, 1e-9, 999.9995, 1e12]])
+    vals = vals.astype(np.float32)
+    vals = vals[: (vals.size // 7) * 7].reshape(-1, 7)
+    _roundtrip(tmp_path, vals, ".3f", lambda x: f"{x:.3f}")
+
+
+def test_write_fixed3_float64_quotients(tmp_path):
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 500, size=(3000, 5)).astype(np.float64)
+    b = rng.integers(0, 5000, size=(3000, 5)).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = a / (a + b)
+    q[0, 0] = 0.0625
+    q[0, 1] = 0.1235
+    _roundtrip(tmp_path, q, ".3f", lambda x: f"{x:0.3f}")
+
+
+def test_write_counts(tmp_path):
+    rng = np.random.default_rng(2)
+    c = rng.integers(0, 1 << 24, size=(2000, 6)).astype(np.int32)
+    c[0] = [0, 1, 9, 10, 16777215, 123]
+    _roundtrip(tmp_path, c, ".0f", lambda x: f"{np.float32(x):.0f}")
+    _roundtrip(tmp_path, c.astype(np.float32), ".0f", lambda x: f"{x:.0f}")
+    odd = np.float32([[0.5, 1.5, 2.5, 1e10, 3.4e38, -1.0]])
+    _roundtrip(tmp_path, odd, ".0f", lambda x: f"{x:.0f}")
+
+
+def test_write_numpy_repr(tmp_path):
+    rng = np.random.default_rng(3)
+    mant = rng.random(20000)
+    expo = rng.integers(-320, 300, size=20000)
+    v64 = mant * 10.0 ** expo
+    v64[:12] = [1.0, 0.0, -0.0, 1e16, 9999999999999998.0, 1e-4, 9.999e-5, 1e22, 5e-324, 1.7976931348623157e308, 0.1, 123456.789]
+    v64[12:16] = [np.nan, np.inf, -np.inf, 4.9817526009363926e-11]
+    v64 = v64[: (v64.size // 5) * 5].reshape(-1, 5)
+    _roundtrip(tmp_path, v64, "repr", lambda x: str(x))
+    v32 = (mant[:5000] * 10.0 ** np.clip(expo[:5000], -44, 38)).astype(np.float32).reshape(-1, 5)
+    v32[0] = [0.17800002, 0.33333334, 1e-5, 2.5e-8, 1e16]
+    _roundtrip(tmp_path, v32, "repr", lambda x: str(x))
+
+
+def test_read_matches_numpy_parser(golden_dir, tmp_path):
+    src = os.path.join(golden_dir, "compare", "in_allPS.tsv")
+    header, names, data = textio.read_table_numeric(src, np.float32)
+    rows, ref = [], []
+    with open(src) as fh:
+        h = fh.readline()
+        for line in fh:
+            r = line.strip().split("\t")
+            rows.append(r[0])
+            ref.append(r[1:])
+    want = np.array(ref, dtype="float32")
+    assert header == h and names == rows
+    assert np.array_equal(data, want, equal_nan=True)
+    cnt = os.path.join(golden_dir, "quant_c1", "expected_default", "out_inclusionCounts.tsv")
+    _, names, d64 = textio.read_table_numeric(cnt, np.float64)
+    ref = [ln.rstrip().split("\t") for ln in open(cnt)][1:]
+    assert names == [r[0] for r in ref]
+    assert np.array_equal(d64, np.array([r[1:] for r in ref], dtype=float))
+    # round trip of awkward spellings numpy accepts
+    p = tmp_path / "odd.tsv"
+    p.write_text("cluster\ta\tb\tc\nx\t1e-3\t+2.5\tnan\ny\t-0\tinf\t3\n")
+    _, n2, d = textio.read_table_numeric(str(p), np.float64)
+    assert n2 == ["x", "y"] and d[0, 0] == 1e-3 and d[0, 1] == 2.5 and np.isnan(d[0, 2]) and np.isinf(d[1, 1])
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("cluster\ta\tb\nx\t1\n")
+    from splicedice_amd._ffi import SdiceError
+    with pytest.raises(SdiceError):
+        textio.read_table_numeric(str(bad), np.float64)
+
+
+def test_large_table_is_parallel_and_ordered(tmp_path):
+    rng = np.random.default_rng(4)
+    data = rng.random((150_000, 8)).astype(np.float32)
+    names = [f"j{i}" for i in range(data.shape[0])]
+    path = str(tmp_path / "big.tsv")
+    textio.write_table(path, "cluster\t" + "\t".join("abcdefgh") + "\n", names, data, ".3f")
+    _, back_names, back = textio.read_table_numeric(path, np.float32)
+    assert back_names == names
+    assert np.array_equal(back, (np.rint(data.astype(np.float64) * 1000) / 1000).astype(np.float32))
