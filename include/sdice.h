@@ -151,6 +151,7 @@ int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double* d_q);
 /* BH down each of `cols` columns of a row-major [n, cols] table, in place
  * (pairwise_fisher.py:187-191) */
 int sdice_bh_columns(sdice_ctx* ctx, int64_t n, int64_t cols, double* p_inout);
+int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout);
 
 /* ---- host-side table text I/O (no device, no context): multithreaded, byte-compatible with the
  *      reference's writers  f'{x:.3f}' (SPLICEDICE.py:353, counts_to_ps.py:69), f'{x:.0f}'

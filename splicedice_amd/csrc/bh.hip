@@ -6,45 +6,96 @@
 // (statsmodels is not installable in the build image: "parity unpinned" for this call,
 // cross-checked against scipy.stats.false_discovery_control.)
 //
-// Device: radix sort of the IEEE-754 bit patterns (non-negative doubles order like
-// unsigned integers) with the original index as payload, an elementwise kernel that
-// writes p_(i)/(i/m) in REVERSED order, an inclusive min-scan (on bit patterns, again
-// order preserving), and a scatter back to the original positions.
+// Device: radix sort of the IEEE-754 bit patterns (non-negative doubles order like unsigned
+// integers) with the original index as payload, an elementwise kernel that writes
+// p_(i)/(i/m) in REVERSED order, an inclusive min-scan (on bit patterns, again order
+// preserving), and a scatter back to the original positions.
+// Everything is written for `segs` equally long segments so that the per-pair-column mode of
+// `pairwise` (pairwise_fisher.py:187-191: BH down each of the S(S-1)/2 columns) is one batched
+// pass over the transposed table instead of one sort per column.
 #include "common.h"
-
-int sd_inclusive_min_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, uint64_t* d_out);
+#include <algorithm>
 
 namespace {
 
-__global__ void __launch_bounds__(256) bh_keys_kernel(const double* __restrict__ p, int64_t m,
+__global__ void __launch_bounds__(256) bh_keys_kernel(const double* __restrict__ p, int64_t m, int64_t total,
                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    if (i >= total) return;
     double v = p[i];
     if (v == 0.0) v = 0.0;   // -0.0 -> +0.0
     keys[i] = (uint64_t)__double_as_longlong(v);
-    idx[i] = (uint32_t)i;
+    idx[i] = (uint32_t)(i % m);          // position inside its segment
 }
 
-// raw_rev[m-1-i] = p_(i) / ((i+1)/m)
-__global__ void __launch_bounds__(256) bh_raw_kernel(const uint64_t* __restrict__ sorted, int64_t m,
+// raw_rev[seg][m-1-i] = p_(i) / ((i+1)/m)
+__global__ void __launch_bounds__(256) bh_raw_kernel(const uint64_t* __restrict__ sorted, int64_t m, int64_t total,
                                                      uint64_t* __restrict__ raw_rev) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const double ps = __longlong_as_double((long long)sorted[i]);
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int64_t seg = g / m, i = g - seg * m;
+    const double ps = __longlong_as_double((long long)sorted[g]);
     const double ecdf = (double)(i + 1) / (double)m;
     const double raw = ps / ecdf;
-    raw_rev[m - 1 - i] = (uint64_t)__double_as_longlong(raw);
+    raw_rev[seg * m + (m - 1 - i)] = (uint64_t)__double_as_longlong(raw);
+}
+
+// inclusive running minimum inside every segment (one workgroup per segment, 2048 values per round)
+__global__ void __launch_bounds__(256) seg_minscan_kernel(const uint64_t* __restrict__ in, int64_t m,
+                                                          uint64_t* __restrict__ out) {
+    __shared__ uint64_t wmin[4];
+    __shared__ uint64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t* src = in + (int64_t)blockIdx.x * m;
+    uint64_t* dst = out + (int64_t)blockIdx.x * m;
+    if (tid == 0) carry_s = ~0ull;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 256 * 8) {
+        uint64_t v[8];
+        const int64_t b = base + (int64_t)tid * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (b + q < m) ? src[b + q] : ~0ull;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = v[q] < v[q - 1] ? v[q] : v[q - 1];
+        uint64_t x = v[7];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned lo = (unsigned)(x & 0xffffffffu), hi = (unsigned)(x >> 32);
+            lo = __shfl_up(lo, o); hi = __shfl_up(hi, o);
+            const uint64_t y = ((uint64_t)hi << 32) | lo;
+            if (lane >= o) x = y < x ? y : x;
+        }
+        if (lane == 63) wmin[w] = x;
+        __syncthreads();
+        uint64_t pre = carry_s;
+        for (int k = 0; k < w; ++k) pre = wmin[k] < pre ? wmin[k] : pre;
+        unsigned lo = (unsigned)(x & 0xffffffffu), hi = (unsigned)(x >> 32);
+        lo = __shfl_up(lo, 1); hi = __shfl_up(hi, 1);
+        uint64_t prev = ((uint64_t)hi << 32) | lo;       // inclusive minimum of the lanes before this one
+        if (lane == 0) prev = ~0ull;
+        const uint64_t tpre = prev < pre ? prev : pre;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (b + q < m) dst[b + q] = v[q] < tpre ? v[q] : tpre;
+        __syncthreads();
+        if (tid == 255) {
+            uint64_t tot = pre;
+            tot = x < tot ? x : tot;
+            carry_s = tot;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(256) bh_scatter_kernel(const uint64_t* __restrict__ cummin_rev,
-                                                         const uint32_t* __restrict__ idx, int64_t m,
+                                                         const uint32_t* __restrict__ idx, int64_t m, int64_t total,
                                                          double* __restrict__ q) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    double v = __longlong_as_double((long long)cummin_rev[m - 1 - i]);
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int64_t seg = g / m, i = g - seg * m;
+    double v = __longlong_as_double((long long)cummin_rev[seg * m + (m - 1 - i)]);
     if (v > 1.0) v = 1.0;
-    q[idx[i]] = v;
+    q[seg * m + idx[g]] = v;
 }
 
 __global__ void __launch_bounds__(256) transpose_f64_kernel(const double* __restrict__ in, int64_t rows, int64_t cols,
@@ -64,11 +115,24 @@ __global__ void __launch_bounds__(256) transpose_f64_kernel(const double* __rest
     }
 }
 
+int transpose(sdice_ctx* ctx, const double* in, int64_t rows, int64_t cols, double* out) {
+    const int64_t gx = sd_ceil_div(cols, 32), gy = sd_ceil_div(rows, 32);
+    if (gy > 65535) {
+        sdice_set_error("transpose: more than 2097120 rows per call");
+        return SDICE_ERR_ARG;
+    }
+    SD_LAUNCH(ctx, "transpose_f64_kernel", transpose_f64_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, in, rows, cols,
+              out);
+    return SDICE_OK;
+}
+
 }  // namespace
 
-static int bh_core(sdice_ctx* ctx, int64_t m, const double* d_p, double* d_q) {
+// BH inside each of `segs` contiguous segments of m p-values: d_p[seg*m + i] -> d_q[seg*m + i]
+static int bh_segments(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_p, double* d_q) {
     Arena& A = ctx->arena;
-    const size_t M = (size_t)m;
+    const int64_t total = m * segs;
+    const size_t M = (size_t)total;
     uint64_t* kA = (uint64_t*)A.alloc(M * 8);
     uint64_t* kB = (uint64_t*)A.alloc(M * 8);
     uint64_t* kC = (uint64_t*)A.alloc(M * 8);
@@ -76,13 +140,13 @@ static int bh_core(sdice_ctx* ctx, int64_t m, const double* d_p, double* d_q) {
     uint32_t* vB = (uint32_t*)A.alloc(M * 4);
     uint32_t* vC = (uint32_t*)A.alloc(M * 4);
     if (!kA || !kB || !kC || !vA || !vB || !vC) return SDICE_ERR_NOMEM;
-    const unsigned g = (unsigned)sd_ceil_div(m, 256);
-    SD_LAUNCH(ctx, "bh_keys_kernel", bh_keys_kernel, dim3(g), dim3(256), 0, d_p, m, kA, vA);
-    // p-values live in [0, 1] (or NaN): sign bit and bit 62 never vary, every other digit may
-    SD_TRY(sd_radix_sort_pairs(ctx, m, kA, vA, kB, vB, kC, vC, 0x7fffffffffffffffull));
-    SD_LAUNCH(ctx, "bh_raw_kernel", bh_raw_kernel, dim3(g), dim3(256), 0, kB, m, kA);
-    SD_TRY(sd_inclusive_min_scan_u64(ctx, m, kA, kC));
-    SD_LAUNCH(ctx, "bh_scatter_kernel", bh_scatter_kernel, dim3(g), dim3(256), 0, kC, vB, m, d_q);
+    const unsigned g = (unsigned)sd_ceil_div(total, 256);
+    SD_LAUNCH(ctx, "bh_keys_kernel", bh_keys_kernel, dim3(g), dim3(256), 0, d_p, m, total, kA, vA);
+    // p-values live in [0, 1] (or NaN): the sign bit never varies, every other digit may
+    SD_TRY(sd_radix_sort_pairs_segmented(ctx, m, segs, kA, vA, kB, vB, kC, vC, 0x7fffffffffffffffull));
+    SD_LAUNCH(ctx, "bh_raw_kernel", bh_raw_kernel, dim3(g), dim3(256), 0, kB, m, total, kA);
+    SD_LAUNCH(ctx, "seg_minscan_kernel", seg_minscan_kernel, dim3((unsigned)segs), dim3(256), 0, kA, m, kC);
+    SD_LAUNCH(ctx, "bh_scatter_kernel", bh_scatter_kernel, dim3(g), dim3(256), 0, kC, vB, m, total, d_q);
     return SDICE_OK;
 }
 
@@ -93,7 +157,7 @@ extern "C" int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double
     SD_ARG(d_p && d_q, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
     SD_TRY(ctx->arena.reset(ctx->stream));
-    return bh_core(ctx, m, d_p, d_q);
+    return bh_segments(ctx, m, 1, d_p, d_q);
 }
 
 extern "C" int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q) {
@@ -111,31 +175,64 @@ extern "C" int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q) {
     return rc;
 }
 
+// BH down each column of a row-major [n, cols] device table, in place.  Columns are processed in
+// groups so that the scratch (28 bytes per value) stays within `budget` bytes.
+extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && cols >= 0, "negative size");
+    SD_ARG(n <= 2000000, "more than 2 000 000 rows per column is not supported (transpose grid limit)");
+    if (n == 0 || cols == 0) return SDICE_OK;
+    SD_ARG(d_p_inout, "NULL pointer");
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t budget = (int64_t)48 << 30;                    // scratch bytes per group of columns
+    int64_t group = budget / (n * 44) > 0 ? budget / (n * 44) : 1;   // 2 x 8 (transposed in/out) + 28 sort scratch
+    if (group > cols) group = cols;
+    if (group > 65535) group = 65535;
+    double *d_cm = nullptr, *d_q = nullptr;
+    int rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_cm);
+    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_q);
+    double* d_slab = nullptr;
+    if (rc == SDICE_OK && group < cols) rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_slab);
+    for (int64_t c0 = 0; c0 < cols && rc == SDICE_OK; c0 += group) {
+        const int64_t gc = std::min(group, cols - c0);
+        rc = ctx->arena.reset(ctx->stream);
+        const double* src = d_p_inout;
+        int64_t src_cols = cols;
+        if (rc == SDICE_OK && group < cols) {
+            // gather the column group [c0, c0+gc) into a dense [n, gc] slab first
+            rc = hipMemcpy2DAsync(d_slab, (size_t)gc * 8, d_p_inout + c0, (size_t)cols * 8, (size_t)gc * 8, (size_t)n,
+                                  hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? SDICE_OK : SDICE_ERR_HIP;
+            src = d_slab;
+            src_cols = gc;
+        }
+        if (rc == SDICE_OK) rc = transpose(ctx, src, n, src_cols, d_cm);
+        if (rc == SDICE_OK) rc = bh_segments(ctx, n, gc, d_cm, d_q);
+        if (rc == SDICE_OK) {
+            if (group < cols) {
+                rc = transpose(ctx, d_q, gc, n, d_slab);
+                if (rc == SDICE_OK)
+                    rc = hipMemcpy2DAsync(d_p_inout + c0, (size_t)cols * 8, d_slab, (size_t)gc * 8, (size_t)gc * 8, (size_t)n,
+                                          hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? SDICE_OK : SDICE_ERR_HIP;
+            } else {
+                rc = transpose(ctx, d_q, gc, n, d_p_inout);
+            }
+        }
+    }
+    sdice_dfree(ctx, d_cm); sdice_dfree(ctx, d_q);
+    if (d_slab) sdice_dfree(ctx, d_slab);
+    return rc;
+}
+
 extern "C" int sdice_bh_columns(sdice_ctx* ctx, int64_t n, int64_t cols, double* p_inout) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n >= 0 && cols >= 0, "negative size");
     if (n == 0 || cols == 0) return SDICE_OK;
     SD_ARG(p_inout, "NULL pointer");
-    SD_HIP(hipSetDevice(ctx->device));
-    double *d_rm = nullptr, *d_cm = nullptr, *d_q = nullptr;
+    double* d_rm = nullptr;
     int rc = sdice_dmalloc(ctx, n * cols * 8, (void**)&d_rm);
-    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * cols * 8, (void**)&d_cm);
-    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * cols * 8, (void**)&d_q);
     if (rc == SDICE_OK) rc = sdice_h2d(ctx, d_rm, p_inout, n * cols * 8);
-    if (rc == SDICE_OK) {
-        dim3 g((unsigned)sd_ceil_div(cols, 32), (unsigned)sd_ceil_div(n, 32));
-        hipLaunchKernelGGL(transpose_f64_kernel, g, dim3(256), 0, ctx->stream, d_rm, n, cols, d_cm);
-        for (int64_t c = 0; c < cols && rc == SDICE_OK; ++c) {
-            rc = ctx->arena.reset(ctx->stream);
-            if (rc == SDICE_OK) rc = bh_core(ctx, n, d_cm + c * n, d_q + c * n);
-        }
-        if (rc == SDICE_OK) {
-            dim3 g2((unsigned)sd_ceil_div(n, 32), (unsigned)sd_ceil_div(cols, 32));
-            hipLaunchKernelGGL(transpose_f64_kernel, g2, dim3(256), 0, ctx->stream, d_q, cols, n, d_rm);
-            if (hipGetLastError() != hipSuccess) { sdice_set_error("transpose launch failed"); rc = SDICE_ERR_HIP; }
-        }
-    }
+    if (rc == SDICE_OK) rc = sdice_bh_columns_dev(ctx, n, cols, d_rm);
     if (rc == SDICE_OK) rc = sdice_d2h(ctx, p_inout, d_rm, n * cols * 8);
-    sdice_dfree(ctx, d_rm); sdice_dfree(ctx, d_cm); sdice_dfree(ctx, d_q);
+    sdice_dfree(ctx, d_rm);
     return rc;
 }

@@ -118,5 +118,9 @@ static inline int64_t sd_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b
 int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, const uint32_t* d_vals_in,
                         uint64_t* d_keys_out, uint32_t* d_vals_out, uint64_t* d_keys_tmp, uint32_t* d_vals_tmp,
                         uint64_t bit_mask);
+// the same for `segs` equally long segments of n keys, each sorted independently (contiguous layout)
+int sd_radix_sort_pairs_segmented(sdice_ctx* ctx, int64_t n, int64_t segs, const uint64_t* d_keys_in,
+                                  const uint32_t* d_vals_in, uint64_t* d_keys_out, uint32_t* d_vals_out,
+                                  uint64_t* d_keys_tmp, uint32_t* d_vals_tmp, uint64_t bit_mask);
 // exclusive scan of int64 values (in place allowed): out[i] = sum_{j<i} in[j]; total to d_total if non-null
 int sd_exclusive_scan_i64(sdice_ctx* ctx, int64_t n, const int64_t* d_in, int64_t* d_out, int64_t* d_total);

@@ -26,11 +26,15 @@ constexpr int ROUNDS = 12;                   // keys per lane
 constexpr int TILE = THREADS * ROUNDS;       // 3072 keys per workgroup
 constexpr int WAVE_KEYS = 64 * ROUNDS;       // contiguous keys owned by one wave
 
+// Every kernel takes a segment index in blockIdx.y: `segs` equally long, independently sorted
+// segments of n keys each (segs = 1 for a plain sort; BH per pair column sorts 19 900 at once).
 __global__ void __launch_bounds__(THREADS) radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                                                              int n_tiles, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[RADIX];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
+    keys += (int64_t)blockIdx.y * n;
+    hist += (int64_t)blockIdx.y * RADIX * n_tiles;
     h[tid] = 0;
     __syncthreads();
     const int64_t beg = (int64_t)tile * TILE;
@@ -51,6 +55,8 @@ __global__ void __launch_bounds__(256) radix_binscan_kernel(uint32_t* __restrict
     __shared__ uint32_t carry_s;
     const int bin = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    hist += (int64_t)blockIdx.y * RADIX * n_tiles;
+    bin_total += (int64_t)blockIdx.y * RADIX;
     uint32_t* row = hist + (int64_t)bin * n_tiles;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -90,6 +96,12 @@ __global__ void __launch_bounds__(THREADS) radix_scatter_kernel(const uint64_t* 
     __shared__ uint32_t wsum[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
+    {
+        const int64_t seg_base = (int64_t)blockIdx.y * n;
+        keys_in += seg_base; vals_in += seg_base; keys_out += seg_base; vals_out += seg_base;
+        hist += (int64_t)blockIdx.y * RADIX * n_tiles;
+        bin_total += (int64_t)blockIdx.y * RADIX;
+    }
     const int64_t beg = (int64_t)tile * TILE;
     const int64_t end = min(n, beg + TILE);
     const int64_t wbeg = beg + (int64_t)w * WAVE_KEYS;
@@ -179,12 +191,12 @@ __global__ void __launch_bounds__(THREADS) radix_scatter_kernel(const uint64_t* 
 
 }  // namespace
 
-int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, const uint32_t* d_vals_in,
-                        uint64_t* d_keys_out, uint32_t* d_vals_out, uint64_t* d_keys_tmp, uint32_t* d_vals_tmp,
-                        uint64_t bit_mask) {
-    if (n <= 0) return SDICE_OK;
-    if (n >= ((int64_t)1 << 32)) {
-        sdice_set_error("radix sort: more than 2^32 keys");
+int sd_radix_sort_pairs_segmented(sdice_ctx* ctx, int64_t n, int64_t segs, const uint64_t* d_keys_in,
+                                  const uint32_t* d_vals_in, uint64_t* d_keys_out, uint32_t* d_vals_out,
+                                  uint64_t* d_keys_tmp, uint32_t* d_vals_tmp, uint64_t bit_mask) {
+    if (n <= 0 || segs <= 0) return SDICE_OK;
+    if (n >= ((int64_t)1 << 32) || segs > 65535) {
+        sdice_set_error("radix sort: segment longer than 2^32 keys or more than 65535 segments");
         return SDICE_ERR_ARG;
     }
     // digits that actually vary
@@ -193,14 +205,14 @@ int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, co
         if ((bit_mask >> (8 * d)) & 0xffull) shifts[np++] = 8 * d;
     if (np == 0) {
         if (d_keys_in != d_keys_out) {
-            SD_HIP(hipMemcpyAsync(d_keys_out, d_keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            SD_HIP(hipMemcpyAsync(d_vals_out, d_vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            SD_HIP(hipMemcpyAsync(d_keys_out, d_keys_in, (size_t)(n * segs) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            SD_HIP(hipMemcpyAsync(d_vals_out, d_vals_in, (size_t)(n * segs) * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         return SDICE_OK;
     }
     const int64_t n_tiles = sd_ceil_div(n, TILE);
-    uint32_t* hist = (uint32_t*)ctx->arena.alloc((size_t)RADIX * n_tiles * 4);
-    uint32_t* bin_total = (uint32_t*)ctx->arena.alloc(RADIX * 4);
+    uint32_t* hist = (uint32_t*)ctx->arena.alloc((size_t)segs * RADIX * n_tiles * 4);
+    uint32_t* bin_total = (uint32_t*)ctx->arena.alloc((size_t)segs * RADIX * 4);
     if (!hist || !bin_total) return SDICE_ERR_NOMEM;
     // ping-pong so that the last pass lands in *_out (in, out and tmp must be distinct buffers)
     const uint64_t* kin = d_keys_in;
@@ -209,14 +221,21 @@ int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, co
         const bool to_out = ((np - 1 - p) % 2) == 0;
         uint64_t* kout = to_out ? d_keys_out : d_keys_tmp;
         uint32_t* vout = to_out ? d_vals_out : d_vals_tmp;
-        SD_LAUNCH(ctx, "radix_hist_kernel", radix_hist_kernel, dim3((unsigned)n_tiles), dim3(THREADS), 0, kin, n, shifts[p],
-                  (int)n_tiles, hist);
-        SD_LAUNCH(ctx, "radix_binscan_kernel", radix_binscan_kernel, dim3(RADIX), dim3(256), 0, hist, (int)n_tiles,
-                  bin_total);
-        SD_LAUNCH(ctx, "radix_scatter_kernel", radix_scatter_kernel, dim3((unsigned)n_tiles), dim3(THREADS), 0, kin, vin,
-                  kout, vout, n, shifts[p], (int)n_tiles, hist, bin_total);
+        SD_LAUNCH(ctx, "radix_hist_kernel", radix_hist_kernel, dim3((unsigned)n_tiles, (unsigned)segs), dim3(THREADS), 0, kin,
+                  n, shifts[p], (int)n_tiles, hist);
+        SD_LAUNCH(ctx, "radix_binscan_kernel", radix_binscan_kernel, dim3(RADIX, (unsigned)segs), dim3(256), 0, hist,
+                  (int)n_tiles, bin_total);
+        SD_LAUNCH(ctx, "radix_scatter_kernel", radix_scatter_kernel, dim3((unsigned)n_tiles, (unsigned)segs), dim3(THREADS), 0,
+                  kin, vin, kout, vout, n, shifts[p], (int)n_tiles, hist, bin_total);
         kin = kout;
         vin = vout;
     }
     return SDICE_OK;
+}
+
+int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, const uint32_t* d_vals_in,
+                        uint64_t* d_keys_out, uint32_t* d_vals_out, uint64_t* d_keys_tmp, uint32_t* d_vals_tmp,
+                        uint64_t bit_mask) {
+    return sd_radix_sort_pairs_segmented(ctx, n, 1, d_keys_in, d_vals_in, d_keys_out, d_vals_out, d_keys_tmp, d_vals_tmp,
+                                         bit_mask);
 }

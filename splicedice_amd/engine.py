@@ -250,6 +250,10 @@ class Context:
         n, s = d_incl.shape
         check(self.lib.sdice_fisher_pairs_dev(self.h, n, s, d_incl.ptr, d_excl.ptr, d_p.ptr), "sdice_fisher_pairs_dev")
 
+    def bh_columns_dev(self, d_p):
+        n, cols = d_p.shape
+        check(self.lib.sdice_bh_columns_dev(self.h, n, cols, d_p.ptr), "sdice_bh_columns_dev")
+
     def bh_dev(self, d_p, d_q):
         check(self.lib.sdice_bh_dev(self.h, d_p.shape[0], d_p.ptr, d_q.ptr), "sdice_bh_dev")
 

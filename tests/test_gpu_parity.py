@@ -381,3 +381,16 @@ def test_ps_fast_path_division_is_exact(ctx):
     with np.errstate(invalid="ignore", divide="ignore"):
         w = (a.ravel().astype(np.float64) / (a.ravel() + b.ravel()).astype(np.float64)).astype(np.float32)
     assert np.array_equal(ps2[0::2, 0], w, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,cols", [(3000, 190), (1, 5), (7000, 3), (50, 1000)])
+def test_bh_columns_batched(ctx, n, cols):
+    rng = np.random.default_rng(n + cols)
+    p = rng.random((n, cols)) ** 2
+    p[rng.random((n, cols)) < 0.05] = 1.0
+    if n > 10:
+        p[:4, 0] = p[4, 0]
+    np.testing.assert_allclose(ctx.bh_columns(p), O.bh_columns(p), rtol=1e-14, atol=0)
+    d = ctx.to_device(p)
+    ctx.bh_columns_dev(d)
+    np.testing.assert_allclose(d.to_host(), O.bh_columns(p), rtol=1e-14, atol=0)
