@@ -38,7 +38,10 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# Load the HIP library before anything that could pull in another HIP runtime.
+# The library itself is dlopen'ed when the first Context is created.  At N=1 torch is never
+# imported (HIP runtime of /opt/rocm); at N>1 torch.distributed (gloo control plane) is imported
+# first and the library then binds to the HIP runtime / librccl that torch ships -- both orders
+# were run on MI355X.
 from splicedice_amd.engine import Context  # noqa: E402
 from splicedice_amd import synth  # noqa: E402
 
@@ -250,18 +253,22 @@ class PairwiseWorkload:
         self.alg_bytes = 8.0 * n * self.pairs + 12.0 * n * s     # 8 B per p-value + inputs once
 
     def step(self):
+        # the reference's default pipeline: exclusion sums, Fisher per pair, BH down every pair column
         self.ctx.ps_dev(self.d_counts, self.d_row_ptr, self.d_col, self.d_excl, None)
         self.ctx.fisher_pairs_dev(self.d_counts, self.d_excl, self.d_p)
+        self.ctx.bh_columns_dev(self.d_p)
 
     def describe(self):
         return {"workload": f"pairwise {self.n} junctions x {self.s} samples per GPU = {self.pairs} pairs/junction "
-                            f"(BASELINE config 4 is 200k junctions over 8 GPUs)", "junctions_per_gpu": self.n,
+                            f"(BASELINE config 4 is 200k junctions over 8 GPUs): exclusion sums + Fisher + "
+                            f"BH per pair column (the default --multiple_test_correction)", "junctions_per_gpu": self.n,
                 "samples": self.s}
 
     def verify(self):
         from oracle import oracle_np as O
         m = 2
         cols = 12
+        self.ctx.fisher_pairs_dev(self.d_counts, self.d_excl, self.d_p)     # raw p-values again (d_p holds BH output)
         excl = self.d_excl.to_host()[:m, :cols]
         want = O.fisher_pairs(self.counts[:m, :cols], excl)
         p = self.d_p.to_host()[:m]

@@ -156,7 +156,7 @@ extern "C" int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double
     if (m == 0) return SDICE_OK;
     SD_ARG(d_p && d_q, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
-    SD_TRY(ctx->arena.reset(ctx->stream));
+    SD_TRY(ctx->arena.reserve((size_t)m * 37 + (size_t)(m / 3072 + 2) * 1024 + (1 << 16), ctx->stream));
     return bh_segments(ctx, m, 1, d_p, d_q);
 }
 
@@ -195,7 +195,9 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
     if (rc == SDICE_OK && group < cols) rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_slab);
     for (int64_t c0 = 0; c0 < cols && rc == SDICE_OK; c0 += group) {
         const int64_t gc = std::min(group, cols - c0);
-        rc = ctx->arena.reset(ctx->stream);
+        // 3 x u64 + 3 x u32 per value, per-segment histograms (256 x tiles x 4 B) and bin totals
+        rc = ctx->arena.reserve((size_t)n * gc * 37 + (size_t)gc * ((size_t)(n / 3072 + 2) * 1024 + 1024) + (1 << 16),
+                                ctx->stream);
         const double* src = d_p_inout;
         int64_t src_cols = cols;
         if (rc == SDICE_OK && group < cols) {

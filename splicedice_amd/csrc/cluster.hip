@@ -314,7 +314,9 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
         return SDICE_OK;
     }
     SD_ARG(d_chrom && d_left && d_right && d_strand && d_row_of && d_row_ptr, "NULL pointer");
-    SD_TRY(ctx->arena.reset(ctx->stream));
+    // scratch: 3 x u64 + 3 x u32 keys/values, degrees, generic-path row copies, block maxima, scan
+    // sums, segment table, radix histograms
+    SD_TRY(ctx->arena.reserve((size_t)n * 60 + ((size_t)1 << 24) + (1 << 20), ctx->stream));
     Arena& A = ctx->arena;
     const size_t N = (size_t)n;
     uint64_t* kA = (uint64_t*)A.alloc(N * 8);

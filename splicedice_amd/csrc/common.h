@@ -50,6 +50,9 @@ struct Arena {
     std::vector<Chunk> chunks;
     void* alloc(size_t bytes);   // nullptr on failure (error set)
     int reset(hipStream_t s);
+    // reset + make sure ONE chunk of at least `total` bytes exists (a call that knows its scratch
+    // need up front avoids the grow-by-chunks path and its multi-GB free/alloc at the next reset)
+    int reserve(size_t total, hipStream_t s);
     void release();
 };
 

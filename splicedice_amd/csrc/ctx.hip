@@ -59,6 +59,26 @@ int Arena::reset(hipStream_t s) {
     return SDICE_OK;
 }
 
+int Arena::reserve(size_t total, hipStream_t s) {
+    total = (total + 4095) & ~size_t(4095);
+    if (chunks.size() == 1 && chunks[0].cap >= total) {
+        chunks[0].off = 0;
+        return SDICE_OK;
+    }
+    if (!chunks.empty()) {
+        SD_HIP(hipStreamSynchronize(s));
+        release();
+    }
+    char* p = nullptr;
+    hipError_t e = hipMalloc((void**)&p, total);
+    if (e != hipSuccess) {
+        sdice_set_error("arena: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+        return SDICE_ERR_NOMEM;
+    }
+    chunks.push_back({p, total, 0});
+    return SDICE_OK;
+}
+
 void Arena::release() {
     for (auto& c : chunks) (void)hipFree(c.p);
     chunks.clear();
