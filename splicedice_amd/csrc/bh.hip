@@ -188,16 +188,20 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
     int64_t group = budget / (n * 44) > 0 ? budget / (n * 44) : 1;   // 2 x 8 (transposed in/out) + 28 sort scratch
     if (group > cols) group = cols;
     if (group > 65535) group = 65535;
-    double *d_cm = nullptr, *d_q = nullptr;
-    int rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_cm);
-    if (rc == SDICE_OK) rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_q);
-    double* d_slab = nullptr;
-    if (rc == SDICE_OK && group < cols) rc = sdice_dmalloc(ctx, n * group * 8, (void**)&d_slab);
+    int rc = SDICE_OK;
     for (int64_t c0 = 0; c0 < cols && rc == SDICE_OK; c0 += group) {
         const int64_t gc = std::min(group, cols - c0);
-        // 3 x u64 + 3 x u32 per value, per-segment histograms (256 x tiles x 4 B) and bin totals
-        rc = ctx->arena.reserve((size_t)n * gc * 37 + (size_t)gc * ((size_t)(n / 3072 + 2) * 1024 + 1024) + (1 << 16),
-                                ctx->stream);
+        // everything comes from the context arena (kept between calls: no multi-GB hipMalloc per call):
+        // transposed in/out (+ a dense slab when the columns go in groups), 3 x u64 + 3 x u32 per value
+        // for the sort, per-segment histograms (256 x tiles x 4 B) and bin totals
+        const size_t vals = (size_t)n * (size_t)group;
+        rc = ctx->arena.reserve(vals * (16 + (group < cols ? 8 : 0) + 37) +
+                                    (size_t)group * ((size_t)(n / 3072 + 2) * 1024 + 1024) + (1 << 16), ctx->stream);
+        if (rc != SDICE_OK) break;
+        double* d_cm = (double*)ctx->arena.alloc(vals * 8);
+        double* d_q = (double*)ctx->arena.alloc(vals * 8);
+        double* d_slab = group < cols ? (double*)ctx->arena.alloc(vals * 8) : nullptr;
+        if (!d_cm || !d_q || (group < cols && !d_slab)) return SDICE_ERR_NOMEM;
         const double* src = d_p_inout;
         int64_t src_cols = cols;
         if (rc == SDICE_OK && group < cols) {
@@ -220,8 +224,6 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
             }
         }
     }
-    sdice_dfree(ctx, d_cm); sdice_dfree(ctx, d_q);
-    if (d_slab) sdice_dfree(ctx, d_slab);
     return rc;
 }
 
