@@ -170,6 +170,27 @@ int sdice_table_read(sdice_table* t, char* header, char* names, int64_t* name_of
                      int dtype /* 0 float32, 1 float64 */, int threads);
 int sdice_table_close(sdice_table* t);
 
+/* ---- host-side junction-file parser (no device, no context): one pass over a sample file of
+ *      `splicedice quant` with the reference's per-type admission filters
+ *      (SPLICEDICE.getAllJunctions, SPLICEDICE.py:147-228) and every line's key + score for the
+ *      count pass (SPLICEDICE.getJunctionCounts, SPLICEDICE.py:257-295).
+ *  type: 0 bed / leafcutter, 1 splicedicebed, 2 STAR SJ.out.tab.
+ *  Per line: chrom_id (index into the file's chromosome table, first-appearance order), left, right,
+ *  strand (0 '+', 1 '-', 2 other), score, admit (1 = passes the admission filters).
+ *  sdice_junc_lookup: row of every query junction in rows sorted by (chrom, left, right, strand), -1 if absent. */
+typedef struct sdice_juncfile sdice_juncfile;
+int sdice_junc_open(const char* path, int type, sdice_juncfile** out, int64_t* n_lines, int32_t* n_chroms,
+                    int64_t* chrom_bytes);
+int sdice_junc_read(sdice_juncfile* f, int32_t min_length, int32_t max_length, int32_t min_unique,
+                    int32_t min_overhang, double min_entropy, int no_multimap, int32_t* chrom_id,
+                    int32_t* left, int32_t* right, int8_t* strand, int64_t* score, uint8_t* admit,
+                    char* chrom_names, int64_t* chrom_off /* [n_chroms+1] */, int threads);
+int sdice_junc_close(sdice_juncfile* f);
+int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const int32_t* row_left,
+                      const int32_t* row_right, const int8_t* row_strand, int64_t n_q,
+                      const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
+                      const int8_t* q_strand, int32_t* row_out, int threads);
+
 /* ---- multi-GPU (new; the reference is single-process): one context per rank,
  *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque
  *      bytes created on rank 0 and distributed by the caller (any channel). */

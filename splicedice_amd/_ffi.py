@@ -57,6 +57,11 @@ SIGNATURES = {
     "sdice_table_open": [C.c_char_p, C.POINTER(vp), c_i64p, C.POINTER(C.c_int32), c_i64p, c_i64p],
     "sdice_table_read": [vp, vp, vp, vp, vp, C.c_int, C.c_int],
     "sdice_table_close": [vp],
+    "sdice_junc_open": [C.c_char_p, C.c_int, C.POINTER(vp), c_i64p, C.POINTER(C.c_int32), c_i64p],
+    "sdice_junc_read": [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                        C.c_int],
+    "sdice_junc_close": [vp],
+    "sdice_junc_lookup": [C.c_int64, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int],
     "sdice_comm_unique_id": [ctxp, vp],
     "sdice_comm_init": [ctxp, vp, C.c_int, C.c_int],
     "sdice_comm_destroy": [ctxp],

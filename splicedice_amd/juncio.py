@@ -1,0 +1,122 @@
+"""Junction-file ingestion for `quant` on top of the library's multithreaded parser
+(sdice_junc_open / sdice_junc_read / sdice_junc_lookup; csrc/juncio.cpp).
+
+Same semantics as the reference's two Python passes over every sample file
+(SPLICEDICE.getAllJunctions :147-228, SPLICEDICE.getJunctionCounts :257-295); each file is read
+once.  Everything here is host side.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+TYPE_CODE = {"bed": 0, "leafcutter": 0, "splicedicebed": 1, "SJ": 2}   # other types contribute nothing (:23-36)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def parse_sample(path, type_code, args):
+    """-> dict(chroms list[str], chrom_id i32[n], left i32[n], right i32[n], strand i8[n] (0 '+', 1 '-', 2 other),
+    score i64[n], admit u8[n])"""
+    lib = _ffi.load()
+    h = C.c_void_p()
+    n, nc, cb = C.c_int64(), C.c_int32(), C.c_int64()
+    _ffi.check(lib.sdice_junc_open(str(path).encode(), type_code, C.byref(h), C.byref(n), C.byref(nc), C.byref(cb)),
+               "sdice_junc_open")
+    try:
+        m = n.value
+        out = dict(chrom_id=np.empty(m, np.int32), left=np.empty(m, np.int32), right=np.empty(m, np.int32),
+                   strand=np.empty(m, np.int8), score=np.empty(m, np.int64), admit=np.empty(m, np.uint8))
+        names = C.create_string_buffer(max(1, cb.value))
+        off = np.zeros(nc.value + 1, dtype=np.int64)
+        rc = lib.sdice_junc_read(h, int(args.minLength), int(args.maxLength), int(args.minUnique), int(args.minOverhang),
+                                 float(args.minEntropy), 1 if args.noMultimap else 0, _vp(out["chrom_id"]),
+                                 _vp(out["left"]), _vp(out["right"]), _vp(out["strand"]), _vp(out["score"]),
+                                 _vp(out["admit"]), names, _vp(off), 0)
+        if rc != 0:
+            raise ValueError(f"{path}: {lib.sdice_last_error().decode()}")
+    finally:
+        lib.sdice_junc_close(h)
+    raw = names.raw[:cb.value]
+    out["chroms"] = [raw[off[i]:off[i + 1]].decode() for i in range(nc.value)]
+    return out
+
+
+def lookup_rows(rows, q_chrom, q_left, q_right, q_strand):
+    """rows: (chrom_rank, left, right, strand) arrays sorted in row order -> int32 row per query (-1 absent)"""
+    lib = _ffi.load()
+    rc_, rl, rr, rs = (np.ascontiguousarray(a, dtype=d) for a, d in zip(rows, (np.int32, np.int32, np.int32, np.int8)))
+    qc, ql, qr = (np.ascontiguousarray(a, dtype=np.int32) for a in (q_chrom, q_left, q_right))
+    qs = np.ascontiguousarray(q_strand, dtype=np.int8)
+    out = np.empty(qc.size, dtype=np.int32)
+    _ffi.check(lib.sdice_junc_lookup(rc_.size, _vp(rc_), _vp(rl), _vp(rr), _vp(rs), qc.size, _vp(qc), _vp(ql), _vp(qr),
+                                     _vp(qs), _vp(out), 0), "sdice_junc_lookup")
+    return out
+
+
+def ingest(manifest, args):
+    """All sample files of a manifest -> (chrom_names_sorted, junction arrays in row order
+    (chrom_rank, left, right, strand), parsed per-sample records with global chromosome ranks)."""
+    parsed = []
+    all_names = set()
+    for sample in manifest:
+        code = TYPE_CODE.get(sample.type)
+        rec = parse_sample(sample.filename, code, args) if code is not None else None
+        parsed.append(rec)
+        if rec is not None:
+            all_names.update(rec["chroms"])
+    names = sorted(all_names)                     # Python string order, as the reference's tuple sorts
+    rank = {c: i for i, c in enumerate(names)}
+    keys = []
+    for rec in parsed:
+        if rec is None:
+            continue
+        local = np.fromiter((rank[c] for c in rec["chroms"]), dtype=np.int32, count=len(rec["chroms"]))
+        rec["chrom_rank"] = local[rec["chrom_id"]] if rec["chrom_id"].size else np.zeros(0, np.int32)
+        a = rec["admit"].astype(bool)
+        if a.any():
+            k1 = (rec["chrom_rank"][a].astype(np.int64) << 32) | rec["left"][a].astype(np.int64)
+            k2 = (rec["right"][a].astype(np.int64) << 1) | rec["strand"][a].astype(np.int64)
+            o = np.lexsort((k2, k1))
+            k1, k2 = k1[o], k2[o]
+            first = np.r_[True, (k1[1:] != k1[:-1]) | (k2[1:] != k2[:-1])]
+            keys.append((k1[first], k2[first]))
+    if keys:
+        k1 = np.concatenate([k[0] for k in keys])
+        k2 = np.concatenate([k[1] for k in keys])
+        o = np.lexsort((k2, k1))
+        k1, k2 = k1[o], k2[o]
+        first = np.r_[True, (k1[1:] != k1[:-1]) | (k2[1:] != k2[:-1])]
+        k1, k2 = k1[first], k2[first]
+    else:
+        k1 = k2 = np.zeros(0, np.int64)
+    if k1.size and (k1 < 0).any():
+        raise ValueError("junction coordinates must be non-negative")
+    junc = ((k1 >> 32).astype(np.int32), (k1 & 0xFFFFFFFF).astype(np.int32), (k2 >> 1).astype(np.int32),
+            (k2 & 1).astype(np.int8))
+    return names, junc, parsed
+
+
+def gather_counts(manifest, parsed, rows, args):
+    """counts int32 [N, S] + flat `low` indices; later lines overwrite earlier ones, no score filter
+    (SPLICEDICE.py:257-295)."""
+    n, s = rows[0].size, len(manifest)
+    counts = np.zeros((n, s), dtype=np.int64)
+    low = []
+    for si, (sample, rec) in enumerate(zip(manifest, parsed)):
+        if rec is None or rec["left"].size == 0:
+            continue
+        idx = lookup_rows(rows, rec["chrom_rank"], rec["left"], rec["right"], rec["strand"])
+        ok = idx >= 0
+        counts[idx[ok], si] = rec["score"][ok]          # repeated rows: the last line wins
+        if args.lowCoverageNan and sample.type != "SJ":
+            lo = ok & (rec["score"] < args.minUnique)
+            if lo.any():
+                # a row marked low by an earlier line stays marked even if a later line raises the count
+                low.append(np.unique(idx[lo]).astype(np.int64) * s + si)
+    if counts.size and (counts.min() < 0 or counts.max() >= 2 ** 31):
+        raise ValueError("junction counts must be non-negative and below 2**31")
+    return counts.astype(np.int32), (np.concatenate(low) if low else np.zeros(0, np.int64))

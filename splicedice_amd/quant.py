@@ -14,7 +14,7 @@ from time import time
 
 import numpy as np
 
-from . import textio
+from . import juncio, textio
 from .engine import Context
 
 STRAND_SYMBOL = {"0": "0", "1": "+", "2": "-", "+": "+", "-": "-"}   # SPLICEDICE.py:150
@@ -181,17 +181,19 @@ class Quant:
         print("\tDone", timer.check())
 
         print(f"Getting all junctions from {len(self.manifest)} files...")
-        junction_set = get_all_junctions(self.manifest, self.args)
+        # one multithreaded pass per file (csrc/juncio.cpp) instead of the reference's two Python
+        # passes; get_all_junctions / get_junction_counts below state the same rules in Python
+        chrom_names, junc, parsed = juncio.ingest(self.manifest, self.args)
         print("\tDone", timer.check())
 
-        print(f"Finding clusters from {len(junction_set)} junctions...")
-        junction_list = list(junction_set)
-        _, cr, left, right, strand = textio.junction_arrays(junction_list)
-        row_of, self.row_ptr, self.col = self.ctx.cluster(cr, left, right, strand)
-        self.junctions = [None] * len(junction_list)          # row order (SPLICEDICE.py:96)
-        for i, r in enumerate(row_of):
-            self.junctions[r] = junction_list[i]
-        self.junctionIndex = {j: r for r, j in enumerate(self.junctions)}
+        print(f"Finding clusters from {junc[0].size} junctions...")
+        row_of, self.row_ptr, self.col = self.ctx.cluster(*junc)
+        rows = [np.empty_like(a) for a in junc]
+        for dst, src in zip(rows, junc):
+            dst[row_of] = src                                  # row order (SPLICEDICE.py:96)
+        self.rows = tuple(rows)
+        self.junctions = [(chrom_names[c], int(l), int(r), textio.STRAND_SYM[s])
+                          for c, l, r, s in zip(*(a.tolist() for a in self.rows))]
         self.names = [textio.junction_name(j) for j in self.junctions]
         print("\tDone", timer.check())
 
@@ -204,7 +206,7 @@ class Quant:
         print("\tDone", timer.check())
 
         print("Gathering junction counts...")
-        self.counts, self.low = get_junction_counts(self.manifest, self.junctionIndex, self.args)
+        self.counts, self.low = juncio.gather_counts(self.manifest, parsed, self.rows, self.args)
         print("\tDone", timer.check())
 
         print("Writing inclusion counts...")

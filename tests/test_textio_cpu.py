@@ -107,3 +107,68 @@ def test_large_table_is_parallel_and_ordered(tmp_path):
     _, back_names, back = textio.read_table_numeric(path, np.float32)
     assert back_names == names
     assert np.array_equal(back, (np.rint(data.astype(np.float64) * 1000) / 1000).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------ junction files
+def _quant_args(**over):
+    import argparse
+    a = argparse.Namespace(maxLength=50000, minLength=50, minOverhang=5, drim=False, noMultimap=False,
+                           filter="gtag_only", minUnique=5, lowCoverageNan=False, minEntropy=1)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("variant", ["default", "lowcov_drim", "strict"])
+def test_junction_parser_matches_python_rules(golden_dir, tmp_path, variant):
+    """csrc/juncio.cpp against the reference's rules as restated in quant.get_all_junctions /
+    get_junction_counts (which tests/test_abi_and_host.py pins to the reference's own files)."""
+    import json
+    from splicedice_amd import juncio, quant
+    qdir = os.path.join(golden_dir, "quant_c1")
+    manifest_path = tmp_path / "manifest.tsv"
+    with open(os.path.join(qdir, "manifest.rel.tsv")) as src, open(manifest_path, "w") as dst:
+        for line in src:
+            row = line.rstrip("\n").split("\t")
+            row[1] = os.path.join(qdir, "inputs", row[1])
+            dst.write("\t".join(row) + "\n")
+    args = _quant_args(**json.load(open(os.path.join(qdir, f"expected_{variant}", "args.json"))))
+    manifest = quant.parse_manifest(str(manifest_path))
+    want_set = quant.get_all_junctions(manifest, args)
+    names, junc, parsed = juncio.ingest(manifest, args)
+    got = [(names[c], int(l), int(r), "+-"[s]) for c, l, r, s in zip(*(a.tolist() for a in junc))]
+    assert got == sorted(want_set)                       # the union, already in row order
+    index = {j: i for i, j in enumerate(got)}
+    want_counts, want_low = quant.get_junction_counts(manifest, index, args)
+    counts, low = juncio.gather_counts(manifest, parsed, junc, args)
+    assert np.array_equal(counts, want_counts)
+    assert sorted(set(low.tolist())) == sorted(set(want_low.tolist()))
+
+
+def test_junction_parser_edge_cases(tmp_path):
+    from splicedice_amd import juncio
+    args = _quant_args()
+    p = tmp_path / "a.junc.bed"
+    p.write_text("chr2\t100\t400\te:1.50:1.20;o:20;m:GT_AG;a:?\t9\t+\n"
+                 "chr2\t100\t400\te:1.50:1.20;o:20;m:GT_AG;a:?\t2\t+\n"        # repeated key: last line wins, low score
+                 "chr10\t5\t5000\te:0.10:0.20;o:1;m:GT_AG;a:GENE:1\t1\t-\n"     # annotated: filters do not apply
+                 "chr1\t7\t900\te:1.50:0.20;o:20;m:GT_AG;a:?\t50\t+\n"          # entropy too low
+                 "chr1\t7\t950\te:1.50:1.20;o:20;m:GT_AG;a:?\t50\t.\n")         # strand '.' never admitted
+    rec = juncio.parse_sample(str(p), 1, args)
+    assert rec["chroms"] == ["chr2", "chr10", "chr1"]
+    assert rec["admit"].tolist() == [1, 0, 1, 0, 0] and rec["strand"].tolist() == [0, 0, 1, 0, 2]
+    assert rec["score"].tolist() == [9, 2, 1, 50, 50]
+    sj = tmp_path / "b.SJ.out.tab"
+    sj.write_text("chr1\t101\t400\t1\t1\t1\t4\t3\t30\nchr1\t101\t400\t0\t1\t1\t40\t3\t30\nchr1\t101\t700\t2\t3\t1\t40\t3\t30\n")
+    rec = juncio.parse_sample(str(sj), 2, args)
+    assert rec["left"].tolist() == [100, 100, 100] and rec["score"].tolist() == [7, 43, 43]
+    assert rec["admit"].tolist() == [1, 0, 0] and rec["strand"].tolist() == [0, 2, 1]
+    args.noMultimap = True
+    assert juncio.parse_sample(str(sj), 2, args)["score"].tolist() == [4, 40, 40]
+    bad = tmp_path / "c.bed"
+    bad.write_text("chr1\t10\t20\tx\t5\t+\nchr1\tten\t20\tx\t5\t+\n")
+    with pytest.raises(ValueError, match="malformed line 2"):
+        juncio.parse_sample(str(bad), 0, args)
+    rows = (np.int32([0, 0, 1]), np.int32([5, 5, 1]), np.int32([9, 9, 2]), np.int8([0, 1, 0]))
+    got = juncio.lookup_rows(rows, [0, 1, 0, 2], [5, 1, 5, 1], [9, 2, 8, 2], [1, 0, 0, 0])
+    assert got.tolist() == [1, 2, -1, -1]
