@@ -16,6 +16,8 @@
 #include "common.h"
 #include <algorithm>
 
+int sd_inclusive_min_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, uint64_t* d_out);
+
 namespace {
 
 __global__ void __launch_bounds__(256) bh_keys_kernel(const double* __restrict__ p, int64_t m, int64_t total,
@@ -145,7 +147,11 @@ static int bh_segments(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_
     // p-values live in [0, 1] (or NaN): the sign bit never varies, every other digit may
     SD_TRY(sd_radix_sort_pairs_segmented(ctx, m, segs, kA, vA, kB, vB, kC, vC, 0x7fffffffffffffffull));
     SD_LAUNCH(ctx, "bh_raw_kernel", bh_raw_kernel, dim3(g), dim3(256), 0, kB, m, total, kA);
-    SD_LAUNCH(ctx, "seg_minscan_kernel", seg_minscan_kernel, dim3((unsigned)segs), dim3(256), 0, kA, m, kC);
+    if (segs == 1) {
+        SD_TRY(sd_inclusive_min_scan_u64(ctx, m, kA, kC));      // one long vector: the grid-wide 3-launch scan
+    } else {
+        SD_LAUNCH(ctx, "seg_minscan_kernel", seg_minscan_kernel, dim3((unsigned)segs), dim3(256), 0, kA, m, kC);
+    }
     SD_LAUNCH(ctx, "bh_scatter_kernel", bh_scatter_kernel, dim3(g), dim3(256), 0, kC, vB, m, total, d_q);
     return SDICE_OK;
 }

@@ -82,6 +82,21 @@ __global__ void __launch_bounds__(256) radix_binscan_kernel(uint32_t* __restrict
     if (tid == 0) bin_total[bin] = carry_s;
 }
 
+// Same scan for short segments (n_tiles small): one workgroup per SEGMENT, thread b walks the
+// n_tiles counters of bin b -- instead of 256 workgroups per segment with a handful of values each.
+__global__ void __launch_bounds__(RADIX) radix_binscan_small_kernel(uint32_t* __restrict__ hist, int n_tiles,
+                                                                   uint32_t* __restrict__ bin_total) {
+    hist += (int64_t)blockIdx.x * RADIX * n_tiles;
+    uint32_t* row = hist + (int64_t)threadIdx.x * n_tiles;
+    uint32_t run = 0;
+    for (int i = 0; i < n_tiles; ++i) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    bin_total[(int64_t)blockIdx.x * RADIX + threadIdx.x] = run;
+}
+
 __global__ void __launch_bounds__(THREADS) radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 uint64_t* __restrict__ keys_out,
@@ -223,8 +238,13 @@ int sd_radix_sort_pairs_segmented(sdice_ctx* ctx, int64_t n, int64_t segs, const
         uint32_t* vout = to_out ? d_vals_out : d_vals_tmp;
         SD_LAUNCH(ctx, "radix_hist_kernel", radix_hist_kernel, dim3((unsigned)n_tiles, (unsigned)segs), dim3(THREADS), 0, kin,
                   n, shifts[p], (int)n_tiles, hist);
-        SD_LAUNCH(ctx, "radix_binscan_kernel", radix_binscan_kernel, dim3(RADIX, (unsigned)segs), dim3(256), 0, hist,
-                  (int)n_tiles, bin_total);
+        if (n_tiles <= 64 && segs >= 64) {
+            SD_LAUNCH(ctx, "radix_binscan_small_kernel", radix_binscan_small_kernel, dim3((unsigned)segs), dim3(RADIX), 0,
+                      hist, (int)n_tiles, bin_total);
+        } else {
+            SD_LAUNCH(ctx, "radix_binscan_kernel", radix_binscan_kernel, dim3(RADIX, (unsigned)segs), dim3(256), 0, hist,
+                      (int)n_tiles, bin_total);
+        }
         SD_LAUNCH(ctx, "radix_scatter_kernel", radix_scatter_kernel, dim3((unsigned)n_tiles, (unsigned)segs), dim3(THREADS), 0,
                   kin, vin, kout, vout, n, shifts[p], (int)n_tiles, hist, bin_total);
         kin = kout;
