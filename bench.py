@@ -153,7 +153,7 @@ class QuantWorkload:
     def cpu_baseline(self, sample):
         """Loop-for-loop restatement (oracle) of getClusters + calculatePsi on `sample` junctions, 1 core."""
         from oracle import oracle_np as O
-        m = min(self.n, sample or 400_000, self.sample_counts.shape[0] * 2)
+        m = min(self.n, sample or 1_000_000)        # ~11 s of single-core work at the default size
         # a junction set of its own with the same gene layout (a prefix of the shuffled 1M set
         # would be 25x sparser and have almost no overlaps)
         cr, l, r, st = synth.make_junctions(m, 7)
@@ -216,7 +216,7 @@ class CompareWorkload:
 
     def cpu_baseline(self, sample):
         from oracle import oracle_np as O
-        m = min(self.n, sample or 40_000)
+        m = min(self.n, sample or 100_000, self.sample_ps.shape[0])     # ~16 s of single-core work
         t = time.time()
         r = O.compare_rows(self.sample_ps[:m], self.g1, self.g2)
         O.bh_fdr(r["p"][r["tested"].astype(bool)])
@@ -280,8 +280,8 @@ class PairwiseWorkload:
 
     def cpu_baseline(self, sample):
         from oracle import oracle_np as O
-        m = sample or 3
-        cols = 40
+        m = sample or 20             # ~8 s of single-core work
+        cols = 60
         excl = self.d_excl.to_host()[:m, :cols]
         t = time.time()
         O.fisher_pairs(self.counts[:m, :cols], excl)

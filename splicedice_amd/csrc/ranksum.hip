@@ -260,33 +260,43 @@ __device__ int block_compact(const float* __restrict__ prow, const int32_t* __re
     return base;
 }
 
-// numpy pairwise_sum over a[0..n) in float32, any n, by the whole block; result to all threads
+// numpy's pairwise_sum recursion  `n <= 128 ? leaf : sum(a, n2) + sum(a + n2, n - n2)`,
+// n2 = n/2 - (n/2) % 8, unrolled at compile time to PW_DEPTH levels (n <= 128 << PW_DEPTH).  Every
+// thread walks it redundantly with block-uniform arguments: no stacks, no single-lane section.
+constexpr int PW_DEPTH = 5;
+
+template <int DEPTH>
+__device__ __forceinline__ void pw_leaves(int off, int len, int* leaf_off, int& nl) {
+    if (DEPTH == 0 || len <= 128) {
+        if (threadIdx.x == 0) leaf_off[nl] = off;
+        ++nl;
+    } else {
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        pw_leaves<(DEPTH > 0 ? DEPTH - 1 : 0)>(off, n2, leaf_off, nl);
+        pw_leaves<(DEPTH > 0 ? DEPTH - 1 : 0)>(off + n2, len - n2, leaf_off, nl);
+    }
+}
+
+template <int DEPTH>
+__device__ __forceinline__ float pw_combine(int len, const float* leaf_sum, int& next) {
+    if (DEPTH == 0 || len <= 128) return leaf_sum[next++];
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    const float l = pw_combine<(DEPTH > 0 ? DEPTH - 1 : 0)>(n2, leaf_sum, next);
+    const float r = pw_combine<(DEPTH > 0 ? DEPTH - 1 : 0)>(len - n2, leaf_sum, next);
+    return l + r;
+}
+
+// numpy pairwise_sum over a[0..n) in float32 by the whole block; result to all threads
 __device__ float block_pairwise_sum(const float* a, int n, int* leaf_off /*[LEAF_MAX+1]*/, float* leaf_sum,
                                     float* scratch8 /* [LEAF_MAX*8] */, int leaf_max) {
     const int tid = threadIdx.x;
-    __shared__ int n_leaves_s;
-    __shared__ float result_s;
-    if (tid == 0) {
-        // leaves of the recursion `n2 = n/2; n2 -= n2 % 8; sum(a, n2) + sum(a+n2, n-n2)` in order
-        int st_off[32], st_len[32], sp = 0, nl = 0;
-        st_off[0] = 0; st_len[0] = n; sp = 1;
-        while (sp > 0) {
-            --sp;
-            const int off = st_off[sp], len = st_len[sp];
-            if (len <= 128 || nl >= leaf_max - 1) {
-                leaf_off[nl++] = off;
-            } else {
-                int n2 = len / 2;
-                n2 -= n2 % 8;
-                st_off[sp] = off + n2; st_len[sp] = len - n2; ++sp;   // right, popped second
-                st_off[sp] = off; st_len[sp] = n2; ++sp;             // left, popped first
-            }
-        }
-        leaf_off[nl] = n;
-        n_leaves_s = nl;
-    }
+    (void)leaf_max;
+    int nl = 0;
+    pw_leaves<PW_DEPTH>(0, n, leaf_off, nl);
+    if (tid == 0) leaf_off[nl] = n;
     __syncthreads();
-    const int nl = n_leaves_s;
     for (int t = tid; t < nl * 8; t += blockDim.x) {
         const int L = t >> 3, j = t & 7;
         const int off = leaf_off[L], len = leaf_off[L + 1] - off;
@@ -312,38 +322,9 @@ __device__ float block_pairwise_sum(const float* a, int n, int* leaf_off /*[LEAF
         leaf_sum[L] = res;
     }
     __syncthreads();
-    if (tid == 0) {
-        // re-walk the recursion, combining leaf sums in post-order
-        int st_len[32], st_state[32];
-        float st_val[32];
-        int sp = 0, next = 0;
-        float ret = 0.f;
-        st_len[0] = n; st_state[0] = 0; sp = 1;
-        while (sp > 0) {
-            const int len = st_len[sp - 1];
-            int& state = st_state[sp - 1];
-            if (state == 0) {
-                if (len <= 128 || sp >= 31) { ret = leaf_sum[next++]; --sp; continue; }
-                int n2 = len / 2;
-                n2 -= n2 % 8;
-                state = 1;
-                st_len[sp] = n2; st_state[sp] = 0; ++sp;
-            } else if (state == 1) {
-                st_val[sp - 1] = ret;
-                int n2 = len / 2;
-                n2 -= n2 % 8;
-                state = 2;
-                st_len[sp] = len - n2; st_state[sp] = 0; ++sp;
-            } else {
-                ret = st_val[sp - 1] + ret;
-                --sp;
-            }
-        }
-        result_s = ret;
-    }
-    __syncthreads();
-    const float out = result_s;
-    __syncthreads();
+    int next = 0;
+    const float out = pw_combine<PW_DEPTH>(n, leaf_sum, next);
+    __syncthreads();      // leaf_sum / leaf_off are reused by the next call
     return out;
 }
 
@@ -491,7 +472,8 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
     }
     const int P1 = next_pow2(n1), P2 = next_pow2(n2);
     const int big = n1 > n2 ? n1 : n2;
-    const int leaf_max = big / 56 + 4;   // leaves of numpy's pairwise recursion hold 65..128 values
+    SD_ARG(big <= (128 << 5), "group larger than 4096 samples is not supported");
+    const int leaf_max = 36;             // <= 2^5 leaves of numpy's pairwise recursion (+ sentinel)
     const size_t lds = (size_t)(P1 + P2 + leaf_max * 9) * 4 + (size_t)(leaf_max + 1 + 8) * 4;
     SD_ARG(lds <= 150 * 1024, "groups too large for LDS");
     int64_t blocks = n;
