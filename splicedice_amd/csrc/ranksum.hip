@@ -13,7 +13,9 @@
 //   accumulators per <=128-element block, halving recursion above) divided by n in float32;
 //   it is reproduced operation for operation so the means are bit-identical.
 //
-// Two kernels:
+// Three kernels (auto dispatch: lane for groups <= 64, wave for <= 1024, block above):
+//   ranksum_wave_kernel  (n1, n2 <= 1024): one WAVE per row, 64*E-element bitonic network held
+//       in VGPRs across the wave, no workgroup barriers (see the kernel's comment).
 //   ranksum_lane_kernel  (n1, n2 <= 64): one LANE per row.  A wave stages 64 rows (only the
 //       selected columns) into LDS with a coalesced copy, each lane then compacts its row,
 //       sums it, sorts each group with a fully unrolled bitonic network held in VGPRs
@@ -266,15 +268,15 @@ __device__ int block_compact(const float* __restrict__ prow, const int32_t* __re
 constexpr int PW_DEPTH = 5;
 
 template <int DEPTH>
-__device__ __forceinline__ void pw_leaves(int off, int len, int* leaf_off, int& nl) {
+__device__ __forceinline__ void pw_leaves(int off, int len, int* leaf_off, int& nl, bool writer) {
     if (DEPTH == 0 || len <= 128) {
-        if (threadIdx.x == 0) leaf_off[nl] = off;
+        if (writer) leaf_off[nl] = off;
         ++nl;
     } else {
         int n2 = len / 2;
         n2 -= n2 % 8;
-        pw_leaves<(DEPTH > 0 ? DEPTH - 1 : 0)>(off, n2, leaf_off, nl);
-        pw_leaves<(DEPTH > 0 ? DEPTH - 1 : 0)>(off + n2, len - n2, leaf_off, nl);
+        pw_leaves<(DEPTH > 0 ? DEPTH - 1 : 0)>(off, n2, leaf_off, nl, writer);
+        pw_leaves<(DEPTH > 0 ? DEPTH - 1 : 0)>(off + n2, len - n2, leaf_off, nl, writer);
     }
 }
 
@@ -294,7 +296,7 @@ __device__ float block_pairwise_sum(const float* a, int n, int* leaf_off /*[LEAF
     const int tid = threadIdx.x;
     (void)leaf_max;
     int nl = 0;
-    pw_leaves<PW_DEPTH>(0, n, leaf_off, nl);
+    pw_leaves<PW_DEPTH>(0, n, leaf_off, nl, tid == 0);
     if (tid == 0) leaf_off[nl] = n;
     __syncthreads();
     for (int t = tid; t < nl * 8; t += blockDim.x) {
@@ -412,7 +414,246 @@ __global__ void __launch_bounds__(RB_THREADS) ranksum_block_kernel(const float* 
     }
 }
 
+// ------------------------------------------------------------------ wave-per-row variant
+// 64 < max(n1, n2) <= 64*E: one WAVE per row, E values of a group per lane, no workgroup
+// barrier anywhere.  The sort is a bitonic network over 64*E elements in "blocked" layout
+// (element lane*E + e lives in register e of that lane): compare-exchange distances below E
+// are register-to-register, the others are one cross-lane exchange per register.  The
+// per-wave LDS buffers hold the compacted (then sorted) groups for the mean, the medians and
+// the binary searches of the U statistic.
+#define SD_WAVE_SYNC()                                        \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+template <int E>
+__device__ __forceinline__ void bitonic_wave(float (&a)[E], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const int lj = j / E;
+                const bool upper = (lane & lj) != 0;
+                const bool asc = (lane & (k / E)) == 0;   // k/E == 64 on the last merge: ascending
+                const bool take_min = asc != upper;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float other = __shfl_xor(a[e], lj);
+                    float lo, hi;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a[e]), "v"(other));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a[e]), "v"(other));
+                    a[e] = take_min ? lo : hi;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int l = e ^ j;
+                    if (l > e) {
+                        const bool asc = (k < E) ? ((e & k) == 0) : ((lane & (k / E)) == 0);
+                        float lo, hi;
+                        asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a[e]), "v"(a[l]));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a[e]), "v"(a[l]));
+                        a[e] = asc ? lo : hi;
+                        a[l] = asc ? hi : lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// numpy pairwise_sum of C[0..nv) (nv <= 1024: at most 8 leaves) by one wave: lane = leaf*8 + j
+// owns accumulator j of its leaf; the 8 accumulators are folded with three xor-exchanges, which
+// reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) because float addition is commutative.
+__device__ __forceinline__ float wave_pairwise_sum(const float* C, int nv, int lane, int* leaf_off, float* leaf_sum) {
+    int nl = 0;
+    pw_leaves<3>(0, nv, leaf_off, nl, lane == 0);
+    if (lane == 0) leaf_off[nl] = nv;
+    SD_WAVE_SYNC();
+    const int L = lane >> 3, j = lane & 7;
+    int off = 0, len = 0;
+    if (L < nl) { off = leaf_off[L]; len = leaf_off[L + 1] - off; }
+    const int main_n = len - (len & 7);
+    float r = 0.f;
+    if (len >= 8) {
+        r = C[off + j];
+        for (int i = 8; i < main_n; i += 8) r += C[off + i + j];
+    }
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = (len >= 8 ? main_n : 0); i < len; ++i) r += C[off + i];
+    if (j == 0 && L < nl) leaf_sum[L] = r;
+    SD_WAVE_SYNC();
+    int next = 0;
+    const float out = pw_combine<3>(nv, leaf_sum, next);
+    SD_WAVE_SYNC();
+    return out;
+}
+
+template <int E>
+__global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restrict__ ps, int64_t n, int s,
+                                                           const int32_t* __restrict__ g1, int n1,
+                                                           const int32_t* __restrict__ g2, int n2, int ch,
+                                                           RsOut o) {
+    extern __shared__ __align__(16) float smemw[];
+    constexpr int N = 64 * E;
+    constexpr int WSTRIDE = 2 * N + 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    float* SA = smemw + (size_t)wave * WSTRIDE;
+    float* SB = SA + N;
+    float* leaf_sum = SB + N;                                  // [<= 9]
+    int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);     // [<= 10]
+    const float inf = __builtin_inff();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // the selected columns of this lane (striped: selection k = e*64 + lane), loaded once
+    int idx1[E], idx2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = e * 64 + lane;
+        idx1[e] = k < n1 ? g1[k] : -1;
+        idx2[e] = k < n2 ? g2[k] : -1;
+    }
+    // A wave owns chunks of `ch` consecutive rows.  Lane i keeps the integer / float results of
+    // the chunk's i-th row; after the chunk all `ch` lanes do the double precision finish (z, erfc)
+    // at once and the outputs go out as contiguous runs, instead of one lane per row doing both.
+    const int64_t n_chunks = (n + ch - 1) / ch;
+    for (int64_t c = (int64_t)blockIdx.x * wpb + wave; c < n_chunks; c += (int64_t)gridDim.x * wpb) {
+      const int64_t row0 = c * ch;
+      const int rows_here = (int)min((int64_t)ch, n - row0);
+      int s_nv1 = 0, s_nv2 = 0, s_u2 = 0;
+      float s_med1 = 0.f, s_med2 = 0.f, s_sum1 = 0.f, s_sum2 = 0.f;
+      for (int ri = 0; ri < rows_here; ++ri) {
+        const float* prow = ps + (row0 + ri) * s;
+        float x[E], y[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            x[e] = idx1[e] >= 0 ? prow[idx1[e]] : __builtin_nanf("");
+            y[e] = idx2[e] >= 0 ? prow[idx2[e]] : __builtin_nanf("");
+        }
+        SD_WAVE_SYNC();          // the previous row's readers are done with SA / SB
+        // ordered compaction (NaNs dropped): position = valid values in earlier rounds + lower lanes
+        int nv1 = 0, nv2 = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool v1 = x[e] == x[e];
+            const unsigned long long m1 = __ballot(v1);
+            if (v1) SA[nv1 + __popcll(m1 & lt_mask)] = x[e];
+            nv1 += __popcll(m1);
+            const bool v2 = y[e] == y[e];
+            const unsigned long long m2 = __ballot(v2);
+            if (v2) SB[nv2 + __popcll(m2 & lt_mask)] = y[e];
+            nv2 += __popcll(m2);
+        }
+        SD_WAVE_SYNC();
+        if (nv1 < 3 || nv2 < 3) {          // wave-uniform
+            if (lane == ri) { s_nv1 = nv1; s_nv2 = nv2; }
+            continue;
+        }
+        const float sum1 = wave_pairwise_sum(SA, nv1, lane, leaf_off, leaf_sum);
+        const float sum2 = wave_pairwise_sum(SB, nv2, lane, leaf_off, leaf_sum);
+        // sort group 2 then group 1 through one copy of the network; x ends up holding sorted A
+#pragma nounroll
+        for (int gi = 1; gi >= 0; --gi) {
+            float* S = gi ? SB : SA;
+            const int nv = gi ? nv2 : nv1;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float v = S[lane * E + e];
+                x[e] = (lane * E + e) < nv ? v : inf;
+            }
+            bitonic_wave<E>(x, lane);
+#pragma unroll
+            for (int e = 0; e < E; ++e) S[lane * E + e] = x[e];
+        }
+        SD_WAVE_SYNC();
+        // 2U = sum_i lower_bound(B, a_i) + upper_bound(B, a_i); B is +inf padded to N, so the
+        // searches are fixed-trip and branch-free, E of them interleaved per lane
+        int lb[E], ub[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { lb[e] = 0; ub[e] = 0; }
+#pragma unroll
+        for (int step = N / 2; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float v = SB[lb[e] + step - 1];
+                const float w = SB[ub[e] + step - 1];
+                if (v < x[e]) lb[e] += step;
+                if (w <= x[e]) ub[e] += step;
+            }
+        }
+        int local = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (SB[lb[e]] < x[e]) ++lb[e];
+            if (SB[ub[e]] <= x[e]) ++ub[e];
+            if (lane * E + e < nv1) local += min(lb[e], nv2) + min(ub[e], nv2);
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) local += __shfl_xor(local, ofs);
+        const float med1 = median_sorted(SA, nv1), med2 = median_sorted(SB, nv2);   // broadcast reads
+        if (lane == ri) {
+            s_nv1 = nv1; s_nv2 = nv2; s_u2 = local;
+            s_med1 = med1; s_med2 = med2; s_sum1 = sum1; s_sum2 = sum2;
+        }
+      }
+      if (lane < rows_here) {
+        const int64_t row = row0 + lane;
+        const bool tested = s_nv1 >= 3 && s_nv2 >= 3;
+        float mean1 = 0.f, mean2 = 0.f;
+        if (tested) {
+            mean1 = s_sum1 / (float)s_nv1;
+            mean2 = s_sum2 / (float)s_nv2;
+        }
+        // (2U, n1, n2) travel to ranksum_finish_kernel in the bits of p[row]: the double
+        // precision tail (sqrt, divide, erfc) would otherwise set this kernel's VGPR budget
+        const unsigned long long packed =
+            tested ? ((unsigned long long)(unsigned)s_u2 | ((unsigned long long)s_nv1 << 32) | ((unsigned long long)s_nv2 << 48))
+                   : 0ull;
+        o.tested[row] = tested ? 1 : 0;
+        reinterpret_cast<unsigned long long*>(o.p)[row] = packed;
+        o.med1[row] = s_med1; o.med2[row] = s_med2;
+        o.mean1[row] = mean1; o.mean2[row] = mean2;
+        o.delta[row] = s_med1 - s_med2;
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) ranksum_finish_kernel(int64_t n, double* __restrict__ p_io,
+                                                             double* __restrict__ z_out) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const unsigned long long packed = reinterpret_cast<const unsigned long long*>(p_io)[row];
+    double z = 0.0, p = 0.0;
+    if (packed) rs_finish((int)((packed >> 32) & 0xffff), (int)(packed >> 48), (long long)(packed & 0xffffffffull), z, p);
+    p_io[row] = p;
+    if (z_out) z_out[row] = z;
+}
+
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <int E>
+int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* g1, int n1, const int32_t* g2,
+                int n2, RsOut o) {
+    const int waves = 4;
+    const size_t lds = (size_t)waves * (2 * 64 * E + 32) * 4;
+    // rows per chunk: as many as keeps every wave slot of the chip (32 per CU) busy twice over
+    const int64_t slots = (int64_t)ctx->n_cu * 32;
+    int ch = 64;
+    while (ch > 1 && sd_ceil_div(n, ch) < 2 * slots) ch >>= 1;
+    int64_t blocks = sd_ceil_div(sd_ceil_div(n, ch), waves);
+    const int64_t cap = (int64_t)ctx->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    SD_LAUNCH(ctx, "ranksum_wave_kernel", (ranksum_wave_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
+              s, g1, n1, g2, n2, ch, o);
+    SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
+              o.p, o.z);
+    return SDICE_OK;
+}
 
 template <int P>
 int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2, RsOut o) {
@@ -454,7 +695,7 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         return SDICE_OK;
     }
     SD_ARG(d_ps, "ps is NULL");
-    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block
+    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block, 3 wave
     const bool lane_ok = n1 <= 64 && n2 <= 64;
     SD_ARG(variant != 1 || lane_ok, "lane variant needs n1, n2 <= 64");
     if ((variant == 0 && lane_ok) || variant == 1) {
@@ -470,8 +711,18 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
             default: return launch_lane<64>(ctx, d_ps, n, s, gsel, n1, n2, o);
         }
     }
-    const int P1 = next_pow2(n1), P2 = next_pow2(n2);
     const int big = n1 > n2 ? n1 : n2;
+    SD_ARG(variant != 3 || big <= 1024, "wave variant needs n1, n2 <= 1024");
+    if ((variant == 0 && big <= 1024) || variant == 3) {
+        switch (next_pow2(big < 64 ? 64 : big) / 64) {
+            case 1: return launch_wave<1>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            case 2: return launch_wave<2>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            case 4: return launch_wave<4>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            case 8: return launch_wave<8>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            default: return launch_wave<16>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+        }
+    }
+    const int P1 = next_pow2(n1), P2 = next_pow2(n2);
     SD_ARG(big <= (128 << 5), "group larger than 4096 samples is not supported");
     const int leaf_max = 36;             // <= 2^5 leaves of numpy's pairwise recursion (+ sentinel)
     const size_t lds = (size_t)(P1 + P2 + leaf_max * 9) * 4 + (size_t)(leaf_max + 1 + 8) * 4;
