@@ -135,7 +135,9 @@ class QuantWorkload:
         self.ctx.ps_dev(self.d_counts, self.d_row_ptr, self.d_col, None, self.d_ps)
 
     def describe(self):
-        return {"workload": f"quant {self.n} junctions x {self.s} samples per GPU (BASELINE config 2), cluster+PS",
+        tag = "BASELINE config 2" if (self.n, self.s) == (1_000_000, 100) else \
+            "north_star target size" if (self.n, self.s) == (2_000_000, 500) else "custom size"
+        return {"workload": f"quant {self.n} junctions x {self.s} samples per GPU ({tag}), cluster+PS",
                 "junctions_per_gpu": self.n, "samples": self.s, "avg_overlap_degree": round(self.nnz / self.n, 2)}
 
     def verify(self):
@@ -192,7 +194,7 @@ class CompareWorkload:
         self.d_q = ctx.empty(n, np.float64)
         self.units = n
         if max(self.g1.size, self.g2.size) > 64:
-            self.kernel = "ranksum_block_kernel"
+            self.kernel = "ranksum_wave_kernel" if max(self.g1.size, self.g2.size) <= 1024 else "ranksum_block_kernel"
         self.alg_bytes = (4.0 * s + 28.0) * n          # 4*S_sel + 28 B per junction
 
     def step(self):
