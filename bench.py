@@ -13,7 +13,9 @@ Workloads (BASELINE.json configs):
   compare (config 3)          : 1M rows x (50 v 50) float32 PS table; step = sdice_ranksum_dev
           + sdice_bh_dev; metric = junction tests/s.
   pairwise (config 4 per-GPU shard) : 25k junctions x 200 samples; step = exclusion sums +
-          sdice_fisher_pairs_dev; metric = p-values/s.
+          sdice_fisher_pairs_dev + BH per pair column; metric = p-values/s.
+  e2e     (config 5 per-GPU shard)  : 625k junctions x 1000 samples; step = cluster + PS + quantise
+          + rank-sum (500 v 500) + [RCCL all-gather of p-values at N>1] + BH; metric = PS entries/s.
 
 Multi-GPU: the junction axis is sharded, every rank owns the junctions of its own chromosome
 group (zero halo, no data-path collective inside a step -> weak scaling).  torch.distributed
@@ -53,7 +55,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["quant", "compare", "pairwise"], default="quant")
+    ap.add_argument("--workload", choices=["quant", "compare", "pairwise", "e2e"], default="quant")
     # (long names only: under torch.distributed.run a short "--n" is swallowed by the launcher's parser)
     ap.add_argument("--junctions", dest="n", type=int, default=0, help="junctions per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", dest="s", type=int, default=0, help="samples (default: the BASELINE config)")
@@ -294,7 +296,102 @@ class PairwiseWorkload:
                           f"pairwise_fisher.py:164-179, {dt:.1f} s"}
 
 
-WORKLOADS = {"quant": QuantWorkload, "compare": CompareWorkload, "pairwise": PairwiseWorkload}
+class E2EWorkload(QuantWorkload):
+    """BASELINE config 5, one GPU's shard: quant + compare_sample_sets end to end, device resident.
+
+    step = cluster -> exclusion sums + PS -> '.3f' quantise (the _allPS.tsv text round trip) ->
+    rank-sum (500 v 500) + medians/means -> [N>1: RCCL all-gather of the p-values] -> BH.
+    The PS shard never leaves HBM; only the per-junction p-values are exchanged.
+    """
+    name = "quant + compare_sample_sets end to end"
+    kernel = "ranksum_wave_kernel"
+    needs_comm = True
+
+    def __init__(self, ctx, rank, n, s):
+        # config 5 is 5M junctions x 1000 samples over 8 GPUs -> 625k junctions per GPU
+        super().__init__(ctx, rank, n or 625_000, s or 1000)
+        n, s = self.n, self.s
+        self.g1 = np.arange(0, s // 2, dtype=np.int32)
+        self.g2 = np.arange(s // 2, s, dtype=np.int32)
+        self.d_g1, self.d_g2 = ctx.to_device(self.g1), ctx.to_device(self.g2)
+        self.out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
+                        med1=ctx.empty(n, np.float32), med2=ctx.empty(n, np.float32), mean1=ctx.empty(n, np.float32),
+                        mean2=ctx.empty(n, np.float32), delta=ctx.empty(n, np.float32))
+        self.world = 1
+        self.d_p_all = None
+        self.d_q = ctx.empty(n, np.float64)
+        self.collective = "none (1 GPU)"
+        big = max(self.g1.size, self.g2.size)
+        self.kernel = "ranksum_lane_kernel" if big <= 64 else "ranksum_wave_kernel" if big <= 1024 else "ranksum_block_kernel"
+        self.alg_bytes = (4.0 * s + 28.0) * n           # rank-sum: 4*S_sel + 28 B per junction (SURVEY 8(d))
+
+    def setup_comm(self, dist, world):
+        self.world = world
+        try:
+            uid = self.ctx.comm_unique_id() if dist.rank == 0 else None
+            self.ctx.comm_init(dist.bcast_bytes(uid, 128), dist.rank, world)
+            self.d_p_all = self.ctx.empty(self.n * world, np.float64)
+            self.d_q = self.ctx.empty(self.n * world, np.float64)
+            self.collective = f"RCCL all-gather of {self.n * 8} B of p-values per rank, inside every step"
+        except Exception as e:
+            if os.environ.get("SDICE_BENCH_DEVICE") is None:
+                raise                                   # a real multi-GPU run must not lose its exchange step
+            self.collective = f"skipped (one-GPU rehearsal): {str(e)[:120]}"
+
+    def step(self):
+        super().step()
+        self.ctx.quantize3_dev(self.d_ps)
+        self.ctx.ranksum_dev(self.d_ps, self.d_g1, self.d_g2, self.out)
+        if self.d_p_all is not None:
+            self.ctx.allgather_dev(self.out["p"], self.d_p_all)
+            self.ctx.bh_dev(self.d_p_all, self.d_q)
+        else:
+            self.ctx.bh_dev(self.out["p"], self.d_q)    # untested rows carry p = 0 (same amount of work)
+
+    def describe(self):
+        return {"workload": f"quant + compare end to end, {self.n} junctions x {self.s} samples per GPU "
+                            f"({self.g1.size} v {self.g2.size}; BASELINE config 5 is 5M x 1000 over 8 GPUs): cluster + PS + "
+                            f"quantise + rank-sum + BH", "junctions_per_gpu": self.n, "samples": self.s,
+                "avg_overlap_degree": round(self.nnz / self.n, 2), "collective": self.collective}
+
+    def verify(self):
+        from oracle import oracle_np as O
+        m = 300
+        ps = self.d_ps.offset(0, (m, self.s)).to_host()
+        want = O.compare_rows(ps, self.g1, self.g2)          # the device's own quantised PS rows
+        got = {k: v.to_host()[:m] for k, v in self.out.items()}
+        t = want["tested"].astype(bool)
+        ok = np.array_equal(got["tested"], want["tested"]) and np.array_equal(got["z"][t], want["z"][t]) \
+            and np.allclose(got["p"][t], want["p"][t], rtol=1e-9, atol=0) \
+            and all(np.array_equal(got[k][t], want[k][t]) for k in ("med1", "med2", "mean1", "mean2", "delta"))
+        # and the PS rows themselves: quantised oracle PS of rows whose neighbours are all kept on the host
+        big = min(self.sample_counts.shape[0], 4000)
+        rp = self.d_row_ptr.to_host()[: big + 1]
+        col = self.d_col.to_host()[: int(rp[-1])]
+        inside = np.minimum.reduceat(np.r_[col, 0] < big, np.minimum(rp[:-1], col.size)) | (np.diff(rp) == 0)
+        rows = np.flatnonzero(inside[:m])
+        want_ps, _ = O.calculate_psi_vectorised(self.sample_counts[:big], rp, np.minimum(col, big - 1))
+        ok = ok and np.array_equal(ps[rows], O.quantize3_fast(want_ps[:m])[rows], equal_nan=True)
+        return bool(ok), m
+
+    def cpu_baseline(self, sample):
+        from oracle import oracle_np as O
+        m = min(self.n, sample or 30_000)
+        cr, l, r, st = synth.make_junctions(m, 7)
+        counts = np.resize(self.sample_counts, (m, self.s))
+        t = time.time()
+        row_of, row_ptr, col = O.cluster_csr(cr, l, r, st)
+        ps, _ = O.calculate_psi(counts, row_ptr, col)
+        ps = O.quantize3_fast(ps)
+        res = O.compare_rows(ps, self.g1, self.g2)
+        O.bh_fdr(res["p"][res["tested"].astype(bool)])
+        dt = time.time() - t
+        return {"value": m * self.s / dt, "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": f"{m} junctions x {self.s} samples: oracle get_clusters + calculate_psi + '.3f' round trip + "
+                          f"compare_rows (scipy ranksums per row) + BH, {dt:.1f} s"}
+
+
+WORKLOADS = {"quant": QuantWorkload, "compare": CompareWorkload, "pairwise": PairwiseWorkload, "e2e": E2EWorkload}
 
 
 def traffic_from_profiles(workload, n, s):
@@ -323,6 +420,8 @@ def main():
     forced = os.environ.get("SDICE_BENCH_DEVICE")
     ctx = Context(int(forced) if forced is not None else (dist.local_rank if args.gpus > 1 else 0))
     wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
+    if args.gpus > 1 and getattr(wl, "needs_comm", False):
+        wl.setup_comm(dist, args.gpus)          # this workload has a real exchange step inside every step
 
     for _ in range(args.warmup):
         wl.step()
@@ -347,7 +446,7 @@ def main():
         verify = {"ok": ok, "checked": checked}
 
     allgather = None
-    if args.gpus > 1:
+    if args.gpus > 1 and not getattr(wl, "needs_comm", False):
         # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction)
         try:
             uid = ctx.comm_unique_id() if dist.rank == 0 else None

@@ -61,6 +61,36 @@ class RcclComm:
         return [out[r] for r in range(self.world)]
 
 
+STAT_NAMES = ("tested", "p", "z", "med1", "med2", "mean1", "mean2", "delta")
+_STAT_DTYPES = (np.uint8, np.float64, np.float64, np.float32, np.float32, np.float32, np.float32, np.float32)
+
+
+def _shard_stats(engine, counts_ext, rp, cl, first, k, g1, g2):
+    """PS -> '.3f' quantise -> rank-sum for rows [first, first + k) of one shard (with its halo rows).
+
+    With the HIP Context everything stays in HBM: the counts shard is uploaded once, the PS shard
+    is produced, quantised and consumed in place, and only the 29 B per junction of statistics
+    come back.  (Engines without the device entry points -- the CPU test double of the multi-rank
+    logic -- go through the same three calls on host arrays.)
+    """
+    if not hasattr(engine, "ps_dev"):
+        ps = engine.quantize3(engine.ps(counts_ext, rp, cl))   # the _allPS.tsv text round trip (SURVEY 0.5)
+        return engine.ranksum(ps[first: first + k], g1, g2)
+    n_ext, s = counts_ext.shape
+    d_counts = engine.to_device(counts_ext, np.int32)
+    d_rp, d_cl = engine.to_device(rp, np.int64), engine.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
+    d_ps = engine.empty((n_ext, s), np.float32)
+    engine.ps_dev(d_counts, d_rp, d_cl, None, d_ps)
+    engine.quantize3_dev(d_ps)
+    d_g1, d_g2 = engine.to_device(g1, np.int32), engine.to_device(g2, np.int32)
+    out = {name: engine.empty(k, dt) for name, dt in zip(STAT_NAMES, _STAT_DTYPES)}
+    engine.ranksum_dev(d_ps.offset(first * s, (k, s)), d_g1, d_g2, out)
+    res = {name: out[name].to_host() for name in STAT_NAMES}
+    for a in (d_counts, d_rp, d_cl, d_ps, d_g1, d_g2, *out.values()):
+        a.free()
+    return res
+
+
 def quant_compare_sharded(engine, comm, counts_rows, row_ptr, col, g1, g2):
     """counts_rows int32 [n, s] in output row order (every rank passes the same table; only its
     own slice is touched), CSR over rows, two column groups.
@@ -76,11 +106,9 @@ def quant_compare_sharded(engine, comm, counts_rows, row_ptr, col, g1, g2):
     table = np.zeros((max_rows, STAT_COLS), dtype=np.float64)
     if hi > lo:
         rp, cl = shard.local_csr(row_ptr, col, part)
-        ps = engine.ps(np.ascontiguousarray(counts_rows[elo:ehi]), rp, cl)
-        ps = engine.quantize3(ps)                      # the _allPS.tsv text round trip
-        r = engine.ranksum(ps[lo - elo: hi - elo], g1, g2)
+        r = _shard_stats(engine, np.ascontiguousarray(counts_rows[elo:ehi]), rp, cl, lo - elo, hi - lo, g1, g2)
         k = hi - lo
-        for c, name in enumerate(("tested", "p", "z", "med1", "med2", "mean1", "mean2", "delta")):
+        for c, name in enumerate(STAT_NAMES):
             table[:k, c] = r[name]
     gathered = comm.allgather_rows(table)
     full = np.concatenate([gathered[r][: plan[r]["own_hi"] - plan[r]["own_lo"]] for r in range(comm.world)], axis=0)

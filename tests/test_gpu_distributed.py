@@ -40,6 +40,13 @@ def test_sharded_pipeline_on_engine_matches_oracle(ctx):
         a, b = part["own_lo"] - part["ext_lo"], part["own_hi"] - part["ext_lo"]
         full = O.calculate_psi_vectorised(counts, row_ptr, col)[0]
         assert np.array_equal(loc[a:b], full[part["own_lo"]:part["own_hi"]], equal_nan=True)
+        # and the device-resident shard statistics (PS -> quantise -> rank-sum without leaving HBM)
+        st = distributed._shard_stats(ctx, np.ascontiguousarray(counts[part["ext_lo"]:part["ext_hi"]]), rp, cl, a, b - a,
+                                      g1, g2)
+        sl = slice(part["own_lo"], part["own_hi"])
+        tt = want["tested"][sl].astype(bool)
+        assert np.array_equal(st["tested"], want["tested"][sl]) and np.array_equal(st["z"][tt], want["z"][sl][tt])
+        assert np.array_equal(st["med1"][tt], want["med1"][sl][tt]) and np.array_equal(st["mean2"][tt], want["mean2"][sl][tt])
 
 
 def test_rccl_world1_allgather():
