@@ -51,6 +51,7 @@ struct PsArgs {
     int tiles_per_xcd;  // 0 = no remap
     int n_chunks;       // column chunks per row tile
     int ablate;         // timing experiments only: 1 skip gather, 2 skip staging loads, 4 skip stores
+    int quant3;         // param ps.quantize3: store the '.3f' text round trip of PS (K4 fused into the store)
 };
 
 template <int VEC> struct Vt;
@@ -144,6 +145,9 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
         for (int q = 0; q < VEC; ++q) {
             const unsigned in = comp(own, q);
             o[q] = div_small_ints((float)in, (float)(in + acc[q]));
+            // fused K4: k = rint(ps * 1000) (exact product in float64, half-even as the formatter),
+            // float32(k / 1000.0) == correctly rounded float32 quotient of the two small integers
+            if (a.quant3) o[q] = div_small_ints((float)rint((double)o[q] * 1000.0), 1000.0f);
         }
         if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
     }
@@ -180,7 +184,10 @@ __device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB,
     if (WPS) {
         float o[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) o[q] = ps_value64(comp(own, q), acc[q]);
+        for (int q = 0; q < VEC; ++q) {
+            o[q] = ps_value64(comp(own, q), acc[q]);
+            if (a.quant3) o[q] = (float)(rint((double)o[q] * 1000.0) / 1000.0);
+        }
         if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
     }
     if (WEXCL) store_excl<VEC, unsigned long long>(a.excl + out_index, acc);
@@ -437,6 +444,7 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     int gx = a.n_tiles;
     a.tiles_per_xcd = 0;
     a.ablate = (int)ctx->param("ps.ablate", 0);
+    a.quant3 = (int)ctx->param("ps.quantize3", 0);
     if (ctx->param("ps.xcd_remap", 1) && a.n_tiles >= 64) {
         a.tiles_per_xcd = (int)sd_ceil_div(a.n_tiles, 8);
         gx = a.tiles_per_xcd * 8;

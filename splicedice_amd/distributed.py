@@ -80,8 +80,11 @@ def _shard_stats(engine, counts_ext, rp, cl, first, k, g1, g2):
     d_counts = engine.to_device(counts_ext, np.int32)
     d_rp, d_cl = engine.to_device(rp, np.int64), engine.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
     d_ps = engine.empty((n_ext, s), np.float32)
-    engine.ps_dev(d_counts, d_rp, d_cl, None, d_ps)
-    engine.quantize3_dev(d_ps)
+    engine.set_param("ps.quantize3", 1)          # the '.3f' round trip is fused into the PS store
+    try:
+        engine.ps_dev(d_counts, d_rp, d_cl, None, d_ps)
+    finally:
+        engine.set_param("ps.quantize3", 0)
     d_g1, d_g2 = engine.to_device(g1, np.int32), engine.to_device(g2, np.int32)
     out = {name: engine.empty(k, dt) for name, dt in zip(STAT_NAMES, _STAT_DTYPES)}
     engine.ranksum_dev(d_ps.offset(first * s, (k, s)), d_g1, d_g2, out)

@@ -175,6 +175,26 @@ def test_ps_big_counts_and_zero(ctx):
     assert np.isnan(ps[-1]).all() and np.array_equal(ps, want_ps, equal_nan=True)
 
 
+@pytest.mark.parametrize("n,s,big", [(3000, 100, False), (1500, 300, False), (400, 12, True)])
+def test_ps_fused_quantise(ctx, n, s, big):
+    """param ps.quantize3: the PS store writes float32(f'{ps:.3f}') directly (K4 fused into K3);
+    must equal PS followed by the separate quantise pass, on the 32-bit and the 64-bit sum paths."""
+    cr, left, right, strand = synth.make_junctions(n, 61, n_chrom=3)
+    _, row_ptr, col = O.cluster_csr(cr, left, right, strand)
+    counts = synth.make_counts(n, s, 62)
+    if big:
+        counts = counts * 100000 + 7          # sums beyond 2^24: the float64 path
+    want = O.quantize3_fast(O.calculate_psi_vectorised(counts, row_ptr, col)[0])
+    two_pass = ctx.quantize3(ctx.ps(counts, row_ptr, col))
+    ctx.set_param("ps.quantize3", 1)
+    try:
+        fused = ctx.ps(counts, row_ptr, col)
+    finally:
+        ctx.set_param("ps.quantize3", 0)
+    assert np.array_equal(two_pass, want, equal_nan=True)
+    assert np.array_equal(fused, want, equal_nan=True)
+
+
 def test_ps_empty(ctx):
     ps = ctx.ps(np.zeros((0, 5), np.int32), np.zeros(1, np.int64), np.zeros(0, np.int32))
     assert ps.shape == (0, 5)
