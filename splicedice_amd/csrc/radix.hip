@@ -22,14 +22,17 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / 64;
-constexpr int ROUNDS = 12;                   // keys per lane
-constexpr int TILE = THREADS * ROUNDS;       // 3072 keys per workgroup
-constexpr int WAVE_KEYS = 64 * ROUNDS;       // contiguous keys owned by one wave
+// ROUNDS = keys per lane (template parameter): a workgroup owns a tile of THREADS * ROUNDS keys and
+// each of its waves a contiguous run of 64 * ROUNDS.  12 (3072-key tiles) is the default; 4
+// (param sort.rounds) was tried for small sorts: a 1M-key pass is three ~5 us kernels at the
+// launch/drain floor either way, so smaller tiles do not help there.
 
 // Every kernel takes a segment index in blockIdx.y: `segs` equally long, independently sorted
 // segments of n keys each (segs = 1 for a plain sort; BH per pair column sorts 19 900 at once).
+template <int ROUNDS>
 __global__ void __launch_bounds__(THREADS) radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                                                              int n_tiles, uint32_t* __restrict__ hist) {
+    constexpr int TILE = THREADS * ROUNDS;
     __shared__ uint32_t h[RADIX];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
@@ -97,12 +100,15 @@ __global__ void __launch_bounds__(RADIX) radix_binscan_small_kernel(uint32_t* __
     bin_total[(int64_t)blockIdx.x * RADIX + threadIdx.x] = run;
 }
 
+template <int ROUNDS>
 __global__ void __launch_bounds__(THREADS) radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 uint64_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                                 int n_tiles, const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ bin_total) {
+    constexpr int TILE = THREADS * ROUNDS;
+    constexpr int WAVE_KEYS = 64 * ROUNDS;
     __shared__ uint64_t stage_k[TILE];
     __shared__ uint32_t stage_v[TILE];
     __shared__ uint32_t off[WAVES][RADIX];     // per-wave histogram, then running LDS position per digit
@@ -206,6 +212,39 @@ __global__ void __launch_bounds__(THREADS) radix_scatter_kernel(const uint64_t* 
 
 }  // namespace
 
+template <int ROUNDS>
+static int radix_sort_passes(sdice_ctx* ctx, int64_t n, int64_t segs, const uint64_t* d_keys_in, const uint32_t* d_vals_in,
+                             uint64_t* d_keys_out, uint32_t* d_vals_out, uint64_t* d_keys_tmp, uint32_t* d_vals_tmp,
+                             const int* shifts, int np) {
+    constexpr int TILE = THREADS * ROUNDS;
+    const int64_t n_tiles = sd_ceil_div(n, TILE);
+    uint32_t* hist = (uint32_t*)ctx->arena.alloc((size_t)segs * RADIX * n_tiles * 4);
+    uint32_t* bin_total = (uint32_t*)ctx->arena.alloc((size_t)segs * RADIX * 4);
+    if (!hist || !bin_total) return SDICE_ERR_NOMEM;
+    // ping-pong so that the last pass lands in *_out (in, out and tmp must be distinct buffers)
+    const uint64_t* kin = d_keys_in;
+    const uint32_t* vin = d_vals_in;
+    for (int p = 0; p < np; ++p) {
+        const bool to_out = ((np - 1 - p) % 2) == 0;
+        uint64_t* kout = to_out ? d_keys_out : d_keys_tmp;
+        uint32_t* vout = to_out ? d_vals_out : d_vals_tmp;
+        SD_LAUNCH(ctx, "radix_hist_kernel", (radix_hist_kernel<ROUNDS>), dim3((unsigned)n_tiles, (unsigned)segs),
+                  dim3(THREADS), 0, kin, n, shifts[p], (int)n_tiles, hist);
+        if (n_tiles <= 64 && segs >= 64) {
+            SD_LAUNCH(ctx, "radix_binscan_small_kernel", radix_binscan_small_kernel, dim3((unsigned)segs), dim3(RADIX), 0,
+                      hist, (int)n_tiles, bin_total);
+        } else {
+            SD_LAUNCH(ctx, "radix_binscan_kernel", radix_binscan_kernel, dim3(RADIX, (unsigned)segs), dim3(256), 0, hist,
+                      (int)n_tiles, bin_total);
+        }
+        SD_LAUNCH(ctx, "radix_scatter_kernel", (radix_scatter_kernel<ROUNDS>), dim3((unsigned)n_tiles, (unsigned)segs),
+                  dim3(THREADS), 0, kin, vin, kout, vout, n, shifts[p], (int)n_tiles, hist, bin_total);
+        kin = kout;
+        vin = vout;
+    }
+    return SDICE_OK;
+}
+
 int sd_radix_sort_pairs_segmented(sdice_ctx* ctx, int64_t n, int64_t segs, const uint64_t* d_keys_in,
                                   const uint32_t* d_vals_in, uint64_t* d_keys_out, uint32_t* d_vals_out,
                                   uint64_t* d_keys_tmp, uint32_t* d_vals_tmp, uint64_t bit_mask) {
@@ -225,32 +264,13 @@ int sd_radix_sort_pairs_segmented(sdice_ctx* ctx, int64_t n, int64_t segs, const
         }
         return SDICE_OK;
     }
-    const int64_t n_tiles = sd_ceil_div(n, TILE);
-    uint32_t* hist = (uint32_t*)ctx->arena.alloc((size_t)segs * RADIX * n_tiles * 4);
-    uint32_t* bin_total = (uint32_t*)ctx->arena.alloc((size_t)segs * RADIX * 4);
-    if (!hist || !bin_total) return SDICE_ERR_NOMEM;
-    // ping-pong so that the last pass lands in *_out (in, out and tmp must be distinct buffers)
-    const uint64_t* kin = d_keys_in;
-    const uint32_t* vin = d_vals_in;
-    for (int p = 0; p < np; ++p) {
-        const bool to_out = ((np - 1 - p) % 2) == 0;
-        uint64_t* kout = to_out ? d_keys_out : d_keys_tmp;
-        uint32_t* vout = to_out ? d_vals_out : d_vals_tmp;
-        SD_LAUNCH(ctx, "radix_hist_kernel", radix_hist_kernel, dim3((unsigned)n_tiles, (unsigned)segs), dim3(THREADS), 0, kin,
-                  n, shifts[p], (int)n_tiles, hist);
-        if (n_tiles <= 64 && segs >= 64) {
-            SD_LAUNCH(ctx, "radix_binscan_small_kernel", radix_binscan_small_kernel, dim3((unsigned)segs), dim3(RADIX), 0,
-                      hist, (int)n_tiles, bin_total);
-        } else {
-            SD_LAUNCH(ctx, "radix_binscan_kernel", radix_binscan_kernel, dim3(RADIX, (unsigned)segs), dim3(256), 0, hist,
-                      (int)n_tiles, bin_total);
-        }
-        SD_LAUNCH(ctx, "radix_scatter_kernel", radix_scatter_kernel, dim3((unsigned)n_tiles, (unsigned)segs), dim3(THREADS), 0,
-                  kin, vin, kout, vout, n, shifts[p], (int)n_tiles, hist, bin_total);
-        kin = kout;
-        vin = vout;
-    }
-    return SDICE_OK;
+    int64_t rounds = ctx->param("sort.rounds", 0);
+    if (rounds != 4 && rounds != 12) rounds = 12;   // measured: 4 is no faster at 1M keys and 16% slower at 5M
+    if (rounds == 4)
+        return radix_sort_passes<4>(ctx, n, segs, d_keys_in, d_vals_in, d_keys_out, d_vals_out, d_keys_tmp, d_vals_tmp,
+                                    shifts, np);
+    return radix_sort_passes<12>(ctx, n, segs, d_keys_in, d_vals_in, d_keys_out, d_vals_out, d_keys_tmp, d_vals_tmp, shifts,
+                                 np);
 }
 
 int sd_radix_sort_pairs(sdice_ctx* ctx, int64_t n, const uint64_t* d_keys_in, const uint32_t* d_vals_in,
