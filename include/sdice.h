@@ -200,6 +200,13 @@ int sdice_comm_init(sdice_ctx* ctx, const void* id, int rank, int world);
 int sdice_comm_destroy(sdice_ctx* ctx);
 /* all-gather equal-sized row shards: recv holds world * bytes_per_rank */
 int sdice_allgather_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+/* All-to-all of equal blocks: block q of d_send (bytes_per_peer each) goes to rank q, block r of
+ * d_recv comes from rank r.  Used for the rows->columns transpose that `pairwise`'s default
+ * per-pair-column BH (pairwise_fisher.py:187-191) needs when junction rows are sharded. */
+int sdice_alltoall_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_peer);
+/* Strided device copy (pack / unpack a column block of a row-major matrix), async on the ctx stream. */
+int sdice_copy2d_dev(sdice_ctx* ctx, void* d_dst, int64_t dpitch, const void* d_src, int64_t spitch,
+                     int64_t width_bytes, int64_t rows);
 
 /* ---- per-kernel timing with HIP events on the context's stream ---------------------- */
 /* on: 0 = off, 1 = every kernel, 2 = only the dominant kernel of each path (ps_tile_kernel,

@@ -66,6 +66,8 @@ SIGNATURES = {
     "sdice_comm_init": [ctxp, vp, C.c_int, C.c_int],
     "sdice_comm_destroy": [ctxp],
     "sdice_allgather_dev": [ctxp, vp, vp, C.c_int64],
+    "sdice_alltoall_dev": [ctxp, vp, vp, C.c_int64],
+    "sdice_copy2d_dev": [ctxp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64],
     "sdice_prof_enable": [ctxp, C.c_int],
     "sdice_prof_reset": [ctxp],
     "sdice_prof_query": [ctxp, C.c_char_p, c_i64p, c_f64p],

@@ -16,6 +16,9 @@ typedef int (*fn_CommInitRank)(void**, int, sd_ncclUniqueId, int);
 typedef int (*fn_CommDestroy)(void*);
 typedef const char* (*fn_GetErrorString)(int);
 typedef int (*fn_AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, void*, hipStream_t);
+typedef int (*fn_Send)(const void*, size_t, int, int /*peer*/, void*, hipStream_t);
+typedef int (*fn_Recv)(void*, size_t, int, int /*peer*/, void*, hipStream_t);
+typedef int (*fn_Group)(void);
 
 struct Rccl {
     void* lib = nullptr;
@@ -24,6 +27,10 @@ struct Rccl {
     fn_CommDestroy CommDestroy = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
     fn_AllGather AllGather = nullptr;
+    fn_Send Send = nullptr;
+    fn_Recv Recv = nullptr;
+    fn_Group GroupStart = nullptr;
+    fn_Group GroupEnd = nullptr;
 };
 
 Rccl g_rccl;
@@ -42,7 +49,12 @@ int load_rccl() {
     g_rccl.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
     g_rccl.AllGather = (fn_AllGather)dlsym(h, "ncclAllGather");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
+    g_rccl.Send = (fn_Send)dlsym(h, "ncclSend");
+    g_rccl.Recv = (fn_Recv)dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (fn_Group)dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (fn_Group)dlsym(h, "ncclGroupEnd");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.Send ||
+        !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         sdice_set_error("librccl is missing a required symbol");
         dlclose(h);
         return SDICE_ERR_COMM;
@@ -109,5 +121,46 @@ extern "C" int sdice_allgather_dev(sdice_ctx* ctx, const void* d_send, void* d_r
     const int rc = g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, 0 /* ncclInt8 */, ctx->comm, ctx->stream);
     sd_prof_end(ctx, tok);
     if (rc != 0) return nccl_fail("ncclAllGather", rc);
+    return SDICE_OK;
+}
+
+// All-to-all of equal blocks (rows -> columns transpose of the pairwise p-value matrix, SURVEY
+// 8(e) K6): block q of d_send goes to rank q, block r of d_recv comes from rank r.  Grouped
+// ncclSend/ncclRecv pairs: on the xGMI mesh every pair has its own direct link.
+extern "C" int sdice_alltoall_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_peer) {
+    SD_ARG(ctx && bytes_per_peer >= 0, "bad arguments");
+    if (bytes_per_peer == 0) return SDICE_OK;
+    SD_ARG(d_send && d_recv && d_send != d_recv, "NULL or aliased buffers");
+    if (ctx->world == 1 && !ctx->comm) {
+        SD_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, ctx->stream));
+        return SDICE_OK;
+    }
+    SD_ARG(ctx->comm, "communicator not initialised (sdice_comm_init)");
+    int tok = sd_prof_begin(ctx, "rccl_alltoall");
+    int rc = g_rccl.GroupStart();
+    for (int q = 0; q < ctx->world && rc == 0; ++q) {
+        rc = g_rccl.Send((const char*)d_send + (size_t)q * bytes_per_peer, (size_t)bytes_per_peer, 0 /* ncclInt8 */, q,
+                         ctx->comm, ctx->stream);
+        if (rc == 0)
+            rc = g_rccl.Recv((char*)d_recv + (size_t)q * bytes_per_peer, (size_t)bytes_per_peer, 0, q, ctx->comm,
+                             ctx->stream);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    sd_prof_end(ctx, tok);
+    if (rc != 0) return nccl_fail("ncclSend/ncclRecv", rc);
+    if (rc_end != 0) return nccl_fail("ncclGroupEnd", rc_end);
+    return SDICE_OK;
+}
+
+// Strided device copy: `rows` rows of `width_bytes` from a matrix with row pitch spitch into one
+// with row pitch dpitch (packing / unpacking a column block of a row-major matrix).
+extern "C" int sdice_copy2d_dev(sdice_ctx* ctx, void* d_dst, int64_t dpitch, const void* d_src, int64_t spitch,
+                                int64_t width_bytes, int64_t rows) {
+    SD_ARG(ctx && width_bytes >= 0 && rows >= 0, "bad arguments");
+    if (width_bytes == 0 || rows == 0) return SDICE_OK;
+    SD_ARG(d_dst && d_src && dpitch >= width_bytes && spitch >= width_bytes, "bad pointers or pitches");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipMemcpy2DAsync(d_dst, (size_t)dpitch, d_src, (size_t)spitch, (size_t)width_bytes, (size_t)rows,
+                            hipMemcpyDeviceToDevice, ctx->stream));
     return SDICE_OK;
 }

@@ -26,6 +26,9 @@ class SingleComm:
     def allgather_rows(self, table):
         return [table]
 
+    def alltoall(self, blocks):
+        return [blocks[0]]
+
 
 class GlooComm:
     """Host-side all-gather over an initialised torch.distributed (gloo) process group."""
@@ -42,6 +45,15 @@ class GlooComm:
         self.dist.all_gather(outs, t)
         return [o.numpy() for o in outs]
 
+    def alltoall(self, blocks):
+        """blocks[q] (equal shapes) goes to rank q; returns [block from rank r for r in ranks].
+        (gloo has no all_to_all on CPU tensors: one all_gather of the stacked blocks, keep column `rank`.)"""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(np.stack(blocks)))
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [o.numpy()[self.rank] for o in outs]
+
 
 class RcclComm:
     """Device all-gather through the engine context (RCCL over xGMI)."""
@@ -56,6 +68,16 @@ class RcclComm:
         send = self.ctx.to_device(table)
         recv = self.ctx.empty((self.world,) + table.shape, table.dtype)
         self.ctx.allgather_dev(send, recv)
+        self.ctx.sync()
+        out = recv.to_host()
+        return [out[r] for r in range(self.world)]
+
+    def alltoall(self, blocks):
+        """RCCL grouped send/recv (sdice_alltoall_dev): blocks[q] -> rank q over its direct xGMI link."""
+        stack = np.ascontiguousarray(np.stack(blocks))
+        send = self.ctx.to_device(stack)
+        recv = self.ctx.empty(stack.shape, stack.dtype)
+        self.ctx.alltoall_dev(send, recv, stack[0].nbytes)
         self.ctx.sync()
         out = recv.to_host()
         return [out[r] for r in range(self.world)]
@@ -127,3 +149,63 @@ def quant_compare_sharded(engine, comm, counts_rows, row_ptr, col, g1, g2):
     out["corrected"] = corrected
     out["plan"] = plan
     return out
+
+
+def pair_column_ranges(pairs, world):
+    """Pair columns owned by each rank for the column-wise BH: contiguous, near-equal."""
+    return [(q * pairs // world, (q + 1) * pairs // world) for q in range(world)]
+
+
+def pairwise_sharded(engine, comm, counts_rows, row_ptr, col, correction="pairwise"):
+    """`pairwise` with junction rows sharded over ranks.
+
+    counts_rows int32 [n, s] in row order (every rank passes the same table and touches only its
+    slice), CSR over rows.  Every rank computes the exclusion sums and the s(s-1)/2 Fisher
+    p-values of ITS rows.  The reference's default correction is Benjamini-Hochberg down every
+    pair COLUMN over ALL junctions (pairwise_fisher.py:187-191), so the p-value matrix is
+    transposed across ranks: all-to-all (rows -> columns), column BH on complete columns,
+    all-to-all back.  Returns dict(p=corrected [k, pairs] for this rank's own rows, own=(lo, hi),
+    plan=...).  correction: "pairwise" | "none" ("all" ranks the whole n x pairs matrix at once and
+    is not sharded here -- run it on one GPU).
+    """
+    if correction not in ("pairwise", "none"):
+        raise NotImplementedError("sharded pairwise supports --multiple_test_correction pairwise|none")
+    n, s = counts_rows.shape
+    pairs = s * (s - 1) // 2
+    plan = shard.shard_plan(row_ptr, col, comm.world)
+    part = plan[comm.rank]
+    lo, hi, elo, ehi = part["own_lo"], part["own_hi"], part["ext_lo"], part["ext_hi"]
+    k = hi - lo
+    if k > 0:
+        rp, cl = shard.local_csr(row_ptr, col, part)
+        ext = np.ascontiguousarray(counts_rows[elo:ehi])
+        excl = engine.ps(ext, rp, cl, want_excl=True, want_ps=False)
+        p = engine.fisher_pairs(ext[lo - elo: hi - elo], excl[lo - elo: hi - elo])
+    else:
+        p = np.zeros((0, pairs), dtype=np.float64)
+    if correction == "pairwise" and pairs > 0:
+        ranges = pair_column_ranges(pairs, comm.world)
+        rows_of = [q["own_hi"] - q["own_lo"] for q in plan]
+        maxk = max(max(rows_of), 1)
+        maxw = max(max(b - a for a, b in ranges), 1)
+        blocks = []
+        for a, b in ranges:                                   # my rows of rank q's columns
+            blk = np.zeros((maxk, maxw), dtype=np.float64)
+            blk[:k, : b - a] = p[:, a:b]
+            blocks.append(blk)
+        got = comm.alltoall(blocks)                           # rank r's rows of MY columns
+        a, b = ranges[comm.rank]
+        mine = np.concatenate([got[r][: rows_of[r], : b - a] for r in range(comm.world)], axis=0)
+        assert mine.shape == (n, b - a)
+        if mine.size:
+            mine = engine.bh_columns(mine)
+        back, at = [], 0
+        for r in range(comm.world):                           # corrected values go home
+            blk = np.zeros((maxk, maxw), dtype=np.float64)
+            blk[: rows_of[r], : b - a] = mine[at: at + rows_of[r]]
+            at += rows_of[r]
+            back.append(blk)
+        got = comm.alltoall(back)                             # my rows of rank q's columns, corrected
+        for q, (a, b) in enumerate(ranges):
+            p[:, a:b] = got[q][:k, : b - a]
+    return dict(p=p, own=(lo, hi), plan=plan)

@@ -269,3 +269,10 @@ class Context:
 
     def allgather_dev(self, d_send, d_recv):
         check(self.lib.sdice_allgather_dev(self.h, d_send.ptr, d_recv.ptr, d_send.nbytes), "sdice_allgather_dev")
+
+    def alltoall_dev(self, d_send, d_recv, bytes_per_peer):
+        check(self.lib.sdice_alltoall_dev(self.h, d_send.ptr, d_recv.ptr, int(bytes_per_peer)), "sdice_alltoall_dev")
+
+    def copy2d_dev(self, dst_ptr, dpitch, src_ptr, spitch, width_bytes, rows):
+        check(self.lib.sdice_copy2d_dev(self.h, dst_ptr, int(dpitch), src_ptr, int(spitch), int(width_bytes), int(rows)),
+              "sdice_copy2d_dev")

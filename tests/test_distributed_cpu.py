@@ -15,8 +15,15 @@ from oracle import oracle_np as O
 class OracleEngine:
     """Test double with the engine.Context surface used by distributed.quant_compare_sharded."""
 
-    def ps(self, counts, row_ptr, col):
-        return O.calculate_psi_vectorised(counts, row_ptr, col)[0]
+    def ps(self, counts, row_ptr, col, want_excl=False, want_ps=True):
+        ps, excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+        return (ps, excl) if want_excl and want_ps else excl if want_excl else ps
+
+    def fisher_pairs(self, incl, excl):
+        return O.fisher_pairs(incl, excl)
+
+    def bh_columns(self, p):
+        return O.bh_columns(p)
 
     def quantize3(self, ps):
         return O.quantize3_fast(ps)
@@ -80,3 +87,69 @@ def test_sharded_pipeline_equals_single_process(world):
         for k in ("tested", "p", "z", "corrected", "med1", "med2", "mean1", "mean2", "delta"):
             assert np.array_equal(out[k], single[k]), (rank, k)
     assert single["tested"].sum() > 500 and (single["corrected"][single["tested"] == 1] >= single["p"][single["tested"] == 1]).all()
+
+
+# ---------------------------------------------------------------- pairwise: column BH across ranks
+def _pairwise_problem():
+    from splicedice_amd import synth
+    n, s = 260, 6
+    cr, l, r, st = synth.make_junctions(n, 19, n_chrom=2)
+    row_of, row_ptr, col = O.cluster_csr(cr, l, r, st)
+    counts_in = synth.make_counts(n, s, 20, mean=15)
+    counts = np.zeros_like(counts_in)
+    counts[row_of] = counts_in
+    return counts, row_ptr, col
+
+
+def _pairwise_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from splicedice_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, row_ptr, col = _pairwise_problem()
+        res = {}
+        for mode in ("pairwise", "none"):
+            out = distributed.pairwise_sharded(OracleEngine(), distributed.GlooComm(), counts, row_ptr, col, mode)
+            res[mode] = (out["own"], out["p"])
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_pairwise_column_bh_equals_single_process():
+    """rows -> columns all-to-all, BH on complete pair columns, all-to-all back == the unsharded
+    reference semantics (pairwise_fisher.py:164-191)."""
+    import torch.multiprocessing as mp
+    from splicedice_amd import distributed
+    world = 2
+    counts, row_ptr, col = _pairwise_problem()
+    _, excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    raw = O.fisher_pairs(counts, excl)
+    want = {"none": raw, "pairwise": O.bh_columns(raw)}
+    single = distributed.pairwise_sharded(OracleEngine(), distributed.SingleComm(), counts, row_ptr, col, "pairwise")
+    assert single["own"] == (0, counts.shape[0]) and np.array_equal(single["p"], want["pairwise"])
+    with pytest.raises(NotImplementedError):
+        distributed.pairwise_sharded(OracleEngine(), distributed.SingleComm(), counts, row_ptr, col, "all")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pairwise_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    covered = 0
+    for rank, res in results:
+        for mode in ("pairwise", "none"):
+            (lo, hi), got = res[mode]
+            assert np.array_equal(got, want[mode][lo:hi]), (rank, mode)
+        covered += res["none"][0][1] - res["none"][0][0]
+    assert covered == counts.shape[0]
+    assert distributed.pair_column_ranges(15, 4) == [(0, 3), (3, 7), (7, 11), (11, 15)]

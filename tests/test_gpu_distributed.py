@@ -58,3 +58,29 @@ def test_rccl_world1_allgather():
         table = np.arange(40, dtype=np.float64).reshape(5, 8)
         got = comm.allgather_rows(table)
         assert len(got) == 1 and np.array_equal(got[0], table)
+
+
+def test_sharded_pairwise_on_engine(ctx):
+    """pairwise_sharded on the HIP engine (world 1): exclusion sums + Fisher + column BH through the
+    same code path the multi-rank run takes, incl. the library's all-to-all (RcclComm, world 1)."""
+    from splicedice_amd import distributed, synth
+    from splicedice_amd.engine import Context
+    n, s = 700, 9
+    cr, l, r, st = synth.make_junctions(n, 33, n_chrom=2)
+    row_of, row_ptr, col = O.cluster_csr(cr, l, r, st)
+    counts_in = synth.make_counts(n, s, 34, mean=20)
+    counts = np.zeros_like(counts_in)
+    counts[row_of] = counts_in
+    _, excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    raw = O.fisher_pairs(counts[:60], excl[:60])
+    out = distributed.pairwise_sharded(ctx, distributed.SingleComm(), counts, row_ptr, col, "none")
+    np.testing.assert_allclose(out["p"][:60], raw, rtol=1e-9, atol=0)
+    full_raw = out["p"]
+    out = distributed.pairwise_sharded(ctx, distributed.SingleComm(), counts, row_ptr, col, "pairwise")
+    np.testing.assert_allclose(out["p"], O.bh_columns(full_raw), rtol=1e-12, atol=0)
+    with Context(0) as c:
+        comm = distributed.RcclComm(c, 0, 1, lambda b, n_: b)
+        out2 = distributed.pairwise_sharded(c, comm, counts, row_ptr, col, "pairwise")
+        assert np.array_equal(out2["p"], out["p"])
+        blocks = [np.arange(12, dtype=np.float64).reshape(3, 4)]
+        assert np.array_equal(comm.alltoall(blocks)[0], blocks[0])
