@@ -191,6 +191,15 @@ int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const int32_t* r
                       const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
                       const int8_t* q_strand, int32_t* row_out, int threads);
 
+/* ---- K8: `similarity` scoring (similarity.py:25-47).  For every row with sign != 0 (event
+ * significant in the comparison table: p <= 0.05 and delta != 0, similarity.py:13-20) and every
+ * column with a non-NaN PS: counts[c] += 1; scores[c] += (ps < mid) if sign < 0 else (ps > mid).
+ * PS and midpoints are float64: the reference compares Python floats parsed from both tables. */
+int sdice_similarity(sdice_ctx* ctx, int64_t n, int32_t s, const double* ps, const double* mid, const int8_t* sign,
+                     int64_t* scores, int64_t* counts);
+int sdice_similarity_dev(sdice_ctx* ctx, int64_t n, int32_t s, const double* d_ps, const double* d_mid,
+                         const int8_t* d_sign, int64_t* d_scores, int64_t* d_counts);
+
 /* ---- multi-GPU (new; the reference is single-process): one context per rank,
  *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque
  *      bytes created on rank 0 and distributed by the caller (any channel). */

@@ -361,3 +361,29 @@ def bh_columns(p):
     for i in range(p.shape[1]):
         p[:, i] = bh_fdr(p[:, i])
     return p
+
+
+# --------------------------------------------------------------------------------------
+# similarity
+# --------------------------------------------------------------------------------------
+
+def similarity_scores(ps, mid, sign):
+    """similarity.py:24-47 on arrays: ps float64 [n, s] (NaN = "nan" field), per-row midpoint and
+    sign of delta (0 = event not in the comparison).  Loop for loop as the reference."""
+    ps = np.asarray(ps, dtype=np.float64)
+    n, s = ps.shape
+    scores, counts = [0] * s, [0] * s
+    for r in range(n):
+        if sign[r] < 0:
+            for i in range(s):
+                if not np.isnan(ps[r, i]):
+                    counts[i] += 1
+                    if float(ps[r, i]) < mid[r]:
+                        scores[i] += 1
+        elif sign[r] > 0:
+            for i in range(s):
+                if not np.isnan(ps[r, i]):
+                    counts[i] += 1
+                    if float(ps[r, i]) > mid[r]:
+                        scores[i] += 1
+    return np.array(scores, dtype=np.int64), np.array(counts, dtype=np.int64)

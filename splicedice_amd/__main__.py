@@ -3,7 +3,7 @@
 commands do not need pysam/statsmodels just to start.
 
 Sub-commands outside the accelerated path (bam_to_junc_bed, intron_coverage,
-ir_table, findOutliers, subset, similarity, select) are registered by name so that scripts get
+ir_table, findOutliers, subset, select) are registered by name so that scripts get
 a clear message instead of an argparse "invalid choice".
 """
 import argparse
@@ -15,8 +15,9 @@ ACCELERATED = {
     "counts_to_ps": "splicedice_amd.counts_to_ps",
     "compare_sample_sets": "splicedice_amd.compare_sample_sets",
     "pairwise": "splicedice_amd.pairwise",
+    "similarity": "splicedice_amd.similarity",
 }
-NOT_BUILT = ["bam_to_junc_bed", "intron_coverage", "ir_table", "findOutliers", "subset", "similarity", "select"]
+NOT_BUILT = ["bam_to_junc_bed", "intron_coverage", "ir_table", "findOutliers", "subset", "select"]
 
 
 def _not_built(name):

@@ -62,6 +62,8 @@ SIGNATURES = {
                         C.c_int],
     "sdice_junc_close": [vp],
     "sdice_junc_lookup": [C.c_int64, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int],
+    "sdice_similarity": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
+    "sdice_similarity_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
     "sdice_comm_unique_id": [ctxp, vp],
     "sdice_comm_init": [ctxp, vp, C.c_int, C.c_int],
     "sdice_comm_destroy": [ctxp],

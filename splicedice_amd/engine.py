@@ -219,6 +219,15 @@ class Context:
         check(self.lib.sdice_bh_columns(self.h, n, cols, _ptr(out)), "sdice_bh_columns")
         return out
 
+    def similarity(self, ps, mid, sign):
+        """similarity.py:25-47 -> (scores int64[s], counts int64[s]); ps float64 [n, s]"""
+        ps, mid, sign = _c(ps, np.float64), _c(mid, np.float64), _c(sign, np.int8)
+        n, s = ps.shape
+        scores, counts = np.zeros(s, np.int64), np.zeros(s, np.int64)
+        check(self.lib.sdice_similarity(self.h, n, s, _ptr(ps), _ptr(mid), _ptr(sign), _ptr(scores), _ptr(counts)),
+              "sdice_similarity")
+        return scores, counts
+
     # ---------------------------------------------------------------- device entry points
     def cluster_dev(self, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr):
         """-> (DeviceArray col view (ctx-owned), nnz)"""

@@ -306,6 +306,38 @@ def main():
     with open(os.path.join(HERE, "kat_numpy_str.json"), "w") as fh:
         json.dump(dict(f32=[[float(v), str(v)] for v in vals32],
                        f64=[[float(v).hex(), str(v)] for v in vals64]), fh)
+    # ------------------------------------------------------------------ similarity
+    import splicedice.similarity as SIM
+    sdir = fresh(os.path.join(HERE, "similarity"))
+    cdir = os.path.join(HERE, "compare")
+    # (a) the compare fixture scored against its own PS table, without and with a group manifest
+    quiet(SIM.run_with, ns(comparison=os.path.join(cdir, "expected_out.tsv"), allps=os.path.join(cdir, "in_allPS.tsv"),
+                           manifest=None, output=os.path.join(sdir, "expected_scores.tsv")))
+    with open(os.path.join(sdir, "groups.tsv"), "w") as fh:
+        for i in range(0, 12, 2):
+            fh.write(f"samp{i}\tpath{i}\tg{i % 3}\tbatch{i % 4}\n")
+    quiet(SIM.run_with, ns(comparison=os.path.join(cdir, "expected_out.tsv"), allps=os.path.join(cdir, "in_allPS.tsv"),
+                           manifest=os.path.join(sdir, "groups.tsv"), output=os.path.join(sdir, "expected_scores_groups.tsv")))
+    # (b) hand-made comparison table: midpoints that coincide with 3-decimal PS values (strict
+    # comparisons in float64 of the TEXT values), p above the cut-off, zero delta, negative delta
+    with open(os.path.join(sdir, "in_vs.tsv"), "w") as fh:
+        fh.write("event\tmean1\tmean2\tmedian1\tmedian2\tdelta\tp-value\tcorrected\n")
+        fh.write("e0\t0.5\t0.4\t0.5\t0.4\t0.1\t0.01\t0.02\n")            # midpoint 0.45, delta > 0
+        fh.write("e1\t0.2\t0.6\t0.2\t0.6\t-0.4\t0.001\t0.002\n")         # midpoint 0.4, delta < 0
+        fh.write("e2\t0.2\t0.6\t0.2\t0.6\t-0.4\t0.06\t0.5\n")            # p > 0.05 -> ignored
+        fh.write("e3\t0.3\t0.3\t0.3\t0.3\t0.0\t0.01\t0.02\n")            # delta == 0 -> ignored
+        fh.write("e4\t0.17800002\t0.5\t0.167\t0.5545\t-0.3875\t0.05\t0.05\n")  # p == 0.05 kept
+        fh.write("not_in_table\t0.1\t0.2\t0.1\t0.2\t-0.1\t0.01\t0.01\n")
+    with open(os.path.join(sdir, "in_allPS.tsv"), "w") as fh:
+        fh.write("cluster\ta\tb\tc\td\te\n")
+        fh.write("e0\t0.450\t0.449\t0.451\tnan\t1.000\n")
+        fh.write("e1\t0.400\t0.399\t0.401\t0.000\tnan\n")
+        fh.write("e2\t0.100\t0.100\t0.100\t0.100\t0.100\n")
+        fh.write("e3\t0.100\t0.100\t0.100\t0.100\t0.100\n")
+        fh.write("e4\t0.361\t0.360\t0.36075\tnan\t0.362\n")
+        fh.write("extra\t0.5\t0.5\t0.5\t0.5\t0.5\n")
+    quiet(SIM.run_with, ns(comparison=os.path.join(sdir, "in_vs.tsv"), allps=os.path.join(sdir, "in_allPS.tsv"),
+                           manifest=None, output=os.path.join(sdir, "expected_scores_handmade.tsv")))
     print("golden fixtures written under", HERE)
 
 

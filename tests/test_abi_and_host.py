@@ -161,8 +161,10 @@ def test_dispatcher_names_and_flags():
     assert a.annotation == ""
     a = p.parse_args(["counts_to_ps", "-i", "c", "-o", "o", "-r"])
     assert a.recluster and a.clusters is None
-    for name in ("bam_to_junc_bed", "intron_coverage", "ir_table", "findOutliers", "subset", "similarity", "select"):
+    for name in ("bam_to_junc_bed", "intron_coverage", "ir_table", "findOutliers", "subset", "select"):
         assert p.parse_args([name]).command == name
+    a = p.parse_args(["similarity", "-c", "vs.tsv", "-a", "allps.tsv", "-o", "out.tsv"])
+    assert a.manifest is None and a.comparison == "vs.tsv"
 
 
 # ----------------------------------------------------------------------------------- shard plan

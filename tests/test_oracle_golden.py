@@ -195,3 +195,24 @@ def test_chi2_restatement_vs_scipy_and_reference_output(golden_dir):
         for line, row in zip(fh, p):
             want = np.array([float(x) for x in line.rstrip("\n").split("\t")[1:]])
             np.testing.assert_allclose(row, want, rtol=1e-12, atol=0)
+
+
+def test_similarity_restatement_vs_reference_output(golden_dir):
+    """oracle similarity_scores + the host reading rules reproduce the reference's score files."""
+    from splicedice_amd import similarity as sim
+    s, c = os.path.join(golden_dir, "similarity"), os.path.join(golden_dir, "compare")
+    for vs, allps, want in ((os.path.join(c, "expected_out.tsv"), os.path.join(c, "in_allPS.tsv"), "expected_scores.tsv"),
+                            (os.path.join(s, "in_vs.tsv"), os.path.join(s, "in_allPS.tsv"), "expected_scores_handmade.tsv")):
+        midpoints, deltas = sim.read_vs_file(vs)
+        with open(allps) as fh:
+            samples = fh.readline().rstrip().split("\t")[1:]
+            names, rows = [], []
+            for line in fh:
+                row = line.rstrip().split("\t")
+                names.append(row[0])
+                rows.append([float(x) for x in row[1:]])
+        mid, sign = sim.row_parameters(names, midpoints, deltas)
+        scores, counts = O.similarity_scores(np.array(rows), mid, sign)
+        lines = [f"{sm}\t{sc / ct:0.03f}\t{sc}\t{ct}\n"
+                 for sc, sm, ct in sorted(zip(scores.tolist(), samples, counts.tolist()), reverse=True)]
+        assert "".join(lines) == open(os.path.join(s, want)).read()
