@@ -125,9 +125,14 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
     // all-zero row kept behind the window
     constexpr int GB = 4;
     for (int k = k0; k < k1; k += GB) {
-        int off[GB];
+        // unconditional reads (a short last batch runs into the next row's entries or the words
+        // behind the stage -- always inside the LDS allocation) and a select: predicated reads
+        // compile to an exec-mask round trip per element
+        int raw[GB], off[GB];
 #pragma unroll
-        for (int u = 0; u < GB; ++u) off[u] = (k + u < k1) ? colL[k + u] : zero_off;
+        for (int u = 0; u < GB; ++u) raw[u] = colL[k + u];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) off[u] = (k + u < k1) ? raw[u] : zero_off;
         int mn = off[0];
 #pragma unroll
         for (int u = 1; u < GB; ++u) mn = min(mn, off[u]);

@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restri
         if (rr < n) {
             const bool tested = nv1 >= 3 && nv2 >= 3;
             float med1 = 0.f, med2 = 0.f, dl = 0.f;
-            double z = 0.0, p = 0.0;
+            unsigned long long packed = 0;      // (2U, n1, n2) for ranksum_finish_kernel, as the wave kernel
             if (tested && !(ablate & 1)) {
                 const float* A = row;
                 const float* B = row + n1;
@@ -218,13 +218,12 @@ __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restri
                         av = A[i < nv1 ? i : nv1 - 1];
                     }
                 }
-                rs_finish(nv1, nv2, u2, z, p);
+                packed = (unsigned long long)(unsigned)u2 | ((unsigned long long)nv1 << 32) | ((unsigned long long)nv2 << 48);
             } else {
                 mean1 = 0.f; mean2 = 0.f;
             }
             o.tested[rr] = tested ? 1 : 0;
-            o.p[rr] = p;
-            if (o.z) o.z[rr] = z;
+            reinterpret_cast<unsigned long long*>(o.p)[rr] = packed;
             o.med1[rr] = med1; o.med2[rr] = med2;
             o.mean1[rr] = mean1; o.mean2[rr] = mean2;
             o.delta[rr] = dl;
@@ -668,6 +667,8 @@ int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_LAUNCH(ctx, "ranksum_lane_kernel", (ranksum_lane_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
               s, gsel, n1, n2, stride, o, (int)ctx->param("ranksum.ablate", 0));
+    SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
+              o.p, o.z);
     return SDICE_OK;
 }
 
