@@ -177,7 +177,7 @@ class CompareWorkload:
     metric = "junction rank-sum tests/sec (50 v 50)"
     unit = "rows/s"
     dtype = "f32 PS -> f64 p"
-    kernel = "ranksum_lane_kernel"
+    kernel = "ranksum_pair_kernel"
 
     def __init__(self, ctx, rank, n, s):
         self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
@@ -323,7 +323,7 @@ class E2EWorkload(QuantWorkload):
         self.d_q = ctx.empty(n, np.float64)
         self.collective = "none (1 GPU)"
         big = max(self.g1.size, self.g2.size)
-        self.kernel = "ranksum_lane_kernel" if big <= 64 else "ranksum_wave_kernel" if big <= 1024 else "ranksum_block_kernel"
+        self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_wave_kernel" if big <= 1024 else "ranksum_block_kernel"
         self.alg_bytes = (4.0 * s + 28.0) * n           # rank-sum: 4*S_sel + 28 B per junction
 
     def setup_comm(self, dist, world):

@@ -13,7 +13,9 @@
 //   accumulators per <=128-element block, halving recursion above) divided by n in float32;
 //   it is reproduced operation for operation so the means are bit-identical.
 //
-// Three kernels (auto dispatch: lane for groups <= 64, wave for <= 1024, block above):
+// Kernels (auto dispatch: lane pair for groups <= 64, wave for <= 1024, block above):
+//   ranksum_pair_kernel  (n1, n2 <= 64): the lane kernel's machinery with TWO lanes per row (one
+//       per group), half the LDS per wave, twice the resident waves (see its comment).
 //   ranksum_wave_kernel  (n1, n2 <= 1024): one WAVE per row, 64*E-element bitonic network held
 //       in VGPRs across the wave, no workgroup barriers (see the kernel's comment).
 //   ranksum_lane_kernel  (n1, n2 <= 64): one LANE per row.  A wave stages 64 rows (only the
@@ -227,6 +229,104 @@ __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restri
             o.med1[rr] = med1; o.med2[rr] = med2;
             o.mean1[rr] = mean1; o.mean2[rr] = mean2;
             o.delta[rr] = dl;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ lane-pair variant
+// Same per-lane machinery, but a row is shared by TWO lanes: lane 2r sorts group 1 of row r, lane
+// 2r+1 group 2, so a wave stages 32 rows -- half the LDS per wave and twice the resident waves
+// (the lane kernel's occupancy is set by its LDS tile).  For U the even lane merges with the rule
+// "take b while b <= a" (sum of upper bounds), the odd lane with "b < a" (sum of lower bounds);
+// the pair adds them: 2U = sum_i lb_i + ub_i.  No tie-run bookkeeping in either merge.
+template <int P>
+__global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restrict__ ps, int64_t n, int s,
+                                                           const int32_t* __restrict__ gsel, int n1, int n2,
+                                                           int stride, RsOut o) {
+    extern __shared__ float smemp[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    float* tile = smemp + (size_t)wave * 32 * stride;
+    const int nsel = n1 + n2;
+    int* selL = reinterpret_cast<int*>(smemp + (size_t)waves_per_block * 32 * stride);
+    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    __syncthreads();
+    const int64_t n_groups = (n + 31) >> 5;
+    for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
+         g += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t row0 = g << 5;
+        {   // stage 32 rows x nsel selected columns (lane l owns selected columns l and l + 64)
+            const int rows_avail = (int)min((int64_t)32, n - row0);
+            const float* gbase = ps + row0 * s;
+            const bool act0 = lane < nsel, act1 = lane + 64 < nsel;
+            const int sel0 = act0 ? selL[lane] : 0;
+            const int sel1 = act1 ? selL[lane + 64] : 0;
+            constexpr int RB = 16;
+            for (int r0 = 0; r0 < 32; r0 += RB) {
+                float x0[RB], x1[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int rc = min(r0 + q, rows_avail - 1);
+                    x0[q] = act0 ? gbase[rc * s + sel0] : 0.f;
+                    x1[q] = act1 ? gbase[rc * s + sel1] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = r0 + q;
+                    const bool live = r < rows_avail;
+                    if (act0) tile[r * stride + lane] = live ? x0[q] : __builtin_nanf("");
+                    if (act1) tile[r * stride + lane + 64] = live ? x1[q] : __builtin_nanf("");
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane >> 1, grp = lane & 1;
+        float* row = tile + r * stride;
+        float mean;
+        const int nv = lane_group<P>(row + (grp ? n1 : 0), grp ? n2 : n1, mean);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();          // the partner's sorted group is in LDS
+        const int nv_other = __shfl_xor(nv, 1);
+        const int nv1 = grp ? nv_other : nv, nv2 = grp ? nv : nv_other;
+        const bool tested = nv1 >= 3 && nv2 >= 3;
+        const float* A = row;
+        const float* B = row + n1;
+        float med = 0.f;
+        int part = 0;
+        if (tested) {
+            med = median_sorted(grp ? B : A, nv);
+            int i = 0, j = 0;
+            float av = A[0], bv = B[0];
+            const int steps = nv1 + nv2;
+            for (int t = 0; t < steps; ++t) {
+                const bool before = grp ? (bv < av) : (bv <= av);
+                const bool take_b = j < nv2 && (i >= nv1 || before);
+                if (take_b) {
+                    ++j;
+                    bv = B[j < nv2 ? j : nv2 - 1];
+                } else {
+                    part += j;
+                    ++i;
+                    av = A[i < nv1 ? i : nv1 - 1];
+                }
+            }
+        }
+        const int u2 = part + __shfl_xor(part, 1);
+        const float med_other = __shfl_xor(med, 1);
+        const float mean_other = __shfl_xor(mean, 1);
+        const int64_t rr = row0 + r;
+        if (grp == 0 && rr < n) {
+            const unsigned long long packed =
+                tested ? ((unsigned long long)(unsigned)u2 | ((unsigned long long)nv1 << 32) | ((unsigned long long)nv2 << 48))
+                       : 0ull;
+            o.tested[rr] = tested ? 1 : 0;
+            reinterpret_cast<unsigned long long*>(o.p)[rr] = packed;
+            o.med1[rr] = med; o.med2[rr] = med_other;
+            o.mean1[rr] = tested ? mean : 0.f; o.mean2[rr] = tested ? mean_other : 0.f;
+            o.delta[rr] = med - med_other;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -672,6 +772,23 @@ int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     return SDICE_OK;
 }
 
+template <int P>
+int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2, RsOut o) {
+    const int stride = (n1 + n2) | 1;
+    const int waves = 2;
+    const size_t lds = (size_t)waves * 32 * stride * 4 + (size_t)(n1 + n2) * 4;
+    int64_t blocks = sd_ceil_div(sd_ceil_div(n, 32), waves);
+    const int64_t cap = (int64_t)ctx->n_cu * 24;
+    if (blocks > cap) blocks = cap;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_pair_kernel<P>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ranksum_pair_kernel", (ranksum_pair_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
+              s, gsel, n1, n2, stride, o);
+    SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
+              o.p, o.z);
+    return SDICE_OK;
+}
+
 }  // namespace
 
 extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const float* d_ps, const int32_t* d_g1,
@@ -696,15 +813,23 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         return SDICE_OK;
     }
     SD_ARG(d_ps, "ps is NULL");
-    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block, 3 wave
+    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block, 3 wave, 4 lane pair
     const bool lane_ok = n1 <= 64 && n2 <= 64;
-    SD_ARG(variant != 1 || lane_ok, "lane variant needs n1, n2 <= 64");
-    if ((variant == 0 && lane_ok) || variant == 1) {
+    SD_ARG((variant != 1 && variant != 4) || lane_ok, "lane variants need n1, n2 <= 64");
+    if ((variant == 0 && lane_ok) || variant == 1 || variant == 4) {
         int32_t* gsel = (int32_t*)ctx->arena.alloc((size_t)(n1 + n2) * 4);
         if (!gsel) return SDICE_ERR_NOMEM;
         SD_HIP(hipMemcpyAsync(gsel, d_g1, (size_t)n1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         SD_HIP(hipMemcpyAsync(gsel + n1, d_g2, (size_t)n2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         const int big = n1 > n2 ? n1 : n2;
+        if (variant != 1) {      // auto: the lane-pair kernel (1.45x the lane kernel at 50 v 50, never slower)
+            switch (next_pow2(big < 8 ? 8 : big)) {
+                case 8: return launch_pair<8>(ctx, d_ps, n, s, gsel, n1, n2, o);
+                case 16: return launch_pair<16>(ctx, d_ps, n, s, gsel, n1, n2, o);
+                case 32: return launch_pair<32>(ctx, d_ps, n, s, gsel, n1, n2, o);
+                default: return launch_pair<64>(ctx, d_ps, n, s, gsel, n1, n2, o);
+            }
+        }
         switch (next_pow2(big < 8 ? 8 : big)) {
             case 8: return launch_lane<8>(ctx, d_ps, n, s, gsel, n1, n2, o);
             case 16: return launch_lane<16>(ctx, d_ps, n, s, gsel, n1, n2, o);

@@ -234,7 +234,7 @@ def test_ranksum_kat(ctx, golden_dir):
     for c in json.load(open(os.path.join(golden_dir, "kat_ranksums.json"))):
         x, y = np.float32(c["x"]), np.float32(c["y"])
         row = np.concatenate([x, y])[None, :]
-        for variant in ((0, 2, 3) if max(len(x), len(y)) <= 64 else (2, 3)):
+        for variant in ((0, 2, 3, 4) if max(len(x), len(y)) <= 64 else (2, 3)):
             ctx.set_param("ranksum.variant", variant)
             try:
                 r = ctx.ranksum(row, np.arange(len(x)), np.arange(len(x), len(x) + len(y)))
@@ -251,7 +251,9 @@ def test_ranksum_kat(ctx, golden_dir):
                                               (64, 64, 130, 0), (7, 33, 64, 0), (9, 17, 40, 0), (65, 10, 80, 0),
                                               (500, 500, 1000, 0), (500, 500, 1000, 2), (200, 130, 400, 0),
                                               (200, 130, 400, 2), (1500, 3, 1600, 0), (1024, 1000, 2100, 0),
-                                              (50, 50, 100, 3), (3, 3, 6, 3), (128, 65, 200, 3), (300, 7, 400, 3)])
+                                              (50, 50, 100, 3), (3, 3, 6, 3), (128, 65, 200, 3), (300, 7, 400, 3),
+                                              (50, 50, 100, 4), (3, 3, 6, 4), (64, 64, 130, 4), (7, 33, 64, 4),
+                                              (9, 17, 40, 4), (20, 20, 40, 4)])
 def test_ranksum_vs_oracle(ctx, n1, n2, s, variant):
     n = 700 if s <= 200 else 60
     ps = synth.make_ps_matrix(n, s, seed=n1 * 1000 + n2, nan_frac=0.1)

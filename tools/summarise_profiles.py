@@ -27,7 +27,7 @@ for wl in ("quant", "compare", "pairwise", "e2e"):
 # HBM traffic of every kernel from the two PMC passes.  MI355X_MICROARCH.md (HBM section): both
 # counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream
 # (x2), WRITE_SIZE is exact.
-DOMINANT = {"quant": ("ps_tile_kernel", 1000000, 100), "compare": ("ranksum_lane_kernel", 1000000, 100),
+DOMINANT = {"quant": ("ps_tile_kernel", 1000000, 100), "compare": ("ranksum_pair_kernel", 1000000, 100),
             "pairwise": ("fisher_pairs_kernel", 25000, 200)}
 records = []
 for wl, (dom, n, s) in DOMINANT.items():
