@@ -163,6 +163,15 @@ int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_in
 int sdice_write_table(const char* path, const char* header /* incl. '\n' */, int64_t n, int32_t s,
                       const char* names, const int64_t* name_off, const void* data, int dtype, int mode,
                       int threads /* 0 = all cores */);
+/* Column-major variant: column c is cols[c] (n values) with its own dtype / mode -- the
+ * compare_sample_sets output table mixes float32 and float64 numpy-repr columns
+ * (compareSampleSets.py:252-270). */
+int sdice_write_columns(const char* path, const char* header, int64_t n, const char* names, const int64_t* name_off,
+                        int32_t ncols, const void* const* cols, const int32_t* dtypes, const int32_t* modes, int threads);
+/* `<prefix>_allClusters.tsv` (SPLICEDICE.py:316-326): name<TAB>comma-joined names of the row's
+ * neighbour list (CSR in row indices), one line per junction row. */
+int sdice_write_clusters(const char* path, int64_t n, const char* names, const int64_t* name_off,
+                         const int64_t* row_ptr, const int32_t* col, int threads);
 typedef struct sdice_table sdice_table;
 int sdice_table_open(const char* path, sdice_table** out, int64_t* n, int32_t* s, int64_t* names_bytes,
                      int64_t* header_bytes);
@@ -190,6 +199,12 @@ int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const int32_t* r
                       const int32_t* row_right, const int8_t* row_strand, int64_t n_q,
                       const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
                       const int8_t* q_strand, int32_t* row_out, int threads);
+
+/* ---- K0: sorted set of 64-bit keys, in place: the junction union of `quant`
+ * (`self.junctions.add(...)` over every sample file + `sorted(self.junctions)`, SPLICEDICE.py:147-228,
+ * :96) on order-preserving packed keys chrom|left|right-left|strand.  keys_inout holds n keys on
+ * entry and the *n_unique distinct keys in ascending order on return. */
+int sdice_sort_unique_u64(sdice_ctx* ctx, int64_t n, uint64_t* keys_inout, int64_t* n_unique);
 
 /* ---- K8: `similarity` scoring (similarity.py:25-47).  For every row with sign != 0 (event
  * significant in the comparison table: p <= 0.05 and delta != 0, similarity.py:13-20) and every

@@ -116,6 +116,14 @@ def run_with(args, ctx=None):
             ctx.close()
 
     base_header = "event\tmean1\tmean2\tmedian1\tmedian2\tdelta\tp-value\tcorrected"
+    if not args.annotation:
+        from . import textio
+        # numeric table only: the library's multithreaded formatter (numpy str() of float32 /
+        # float64 per column, byte-identical to the reference's print(*fields, sep="\t"))
+        textio.write_columns(args.outputFile, base_header + "\n", [rows[ri] for ri in keep],
+                             [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
+                             ["repr"] * 7)
+        return
     with open(args.outputFile, "w") as tsv:
         if args.annotation:
             print(base_header + "\tgene\toverlapping\ttranscript_id", file=tsv)

@@ -197,6 +197,129 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
     return SDICE_OK;
 }
 
+// Column-major variant: every column has its own array, dtype and mode (the compare_sample_sets
+// output mixes float32 and float64 numpy-repr columns, compareSampleSets.py:252-270).
+extern "C" int sdice_write_columns(const char* path, const char* header, int64_t n, const char* names,
+                                   const int64_t* name_off, int32_t ncols, const void* const* cols,
+                                   const int32_t* dtypes, const int32_t* modes, int threads) {
+    if (!path || !header || n < 0 || ncols < 0 || (n > 0 && (!names || !name_off)) || (ncols > 0 && (!cols || !dtypes || !modes))) {
+        sdice_set_error("sdice_write_columns: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    for (int32_t c = 0; c < ncols; ++c)
+        if (!cols[c] || dtypes[c] < 0 || dtypes[c] > 2 || modes[c] < 0 || modes[c] > 2 || (dtypes[c] == 2 && modes[c] != 1)) {
+            sdice_set_error("sdice_write_columns: unsupported dtype/mode in column %d", (int)c);
+            return SDICE_ERR_ARG;
+        }
+    FILE* fh = fopen(path, "wb");
+    if (!fh) {
+        sdice_set_error("sdice_write_columns: cannot open %s", path);
+        return SDICE_ERR_ARG;
+    }
+    fwrite(header, 1, strlen(header), fh);
+    const int64_t block = 1 << 16;
+    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    std::vector<std::string> bufs;
+    for (int64_t r0 = 0; r0 < n; r0 += block) {
+        const int64_t nb = std::min(block, n - r0);
+        int used = nb < 4096 ? 1 : std::min(nthreads, 64);
+        if (used < 1) used = 1;
+        bufs.assign(used, std::string());
+        parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
+            std::string& out = bufs[t];
+            out.reserve((size_t)(b - a) * ((size_t)ncols * 20 + 32));
+            for (int64_t r = r0 + a; r < r0 + b; ++r) {
+                out.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+                for (int32_t c = 0; c < ncols; ++c) {
+                    out += '\t';
+                    if (dtypes[c] == 2) {
+                        char b2[16];
+                        auto rr = std::to_chars(b2, b2 + sizeof(b2), ((const int32_t*)cols[c])[r]);
+                        out.append(b2, rr.ptr - b2);
+                    } else if (dtypes[c] == 0) {
+                        const float v = ((const float*)cols[c])[r];
+                        if (modes[c] == 0) put_fixed3(out, (double)v);
+                        else if (modes[c] == 1) put_fixed0(out, (double)v);
+                        else put_repr<float>(out, v);
+                    } else {
+                        const double v = ((const double*)cols[c])[r];
+                        if (modes[c] == 0) put_fixed3(out, v);
+                        else if (modes[c] == 1) put_fixed0(out, v);
+                        else put_repr<double>(out, v);
+                    }
+                }
+                out += '\n';
+            }
+        });
+        for (auto& b : bufs)
+            if (!b.empty() && fwrite(b.data(), 1, b.size(), fh) != b.size()) {
+                fclose(fh);
+                sdice_set_error("sdice_write_columns: short write to %s", path);
+                return SDICE_ERR_ARG;
+            }
+    }
+    if (fclose(fh) != 0) {
+        sdice_set_error("sdice_write_columns: close failed for %s", path);
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+}
+
+// `_allClusters.tsv` (SPLICEDICE.py:316-326): one line per junction row,
+// name<TAB>name_of_neighbour_1,name_of_neighbour_2,...  (a junction without overlaps: name<TAB>).
+extern "C" int sdice_write_clusters(const char* path, int64_t n, const char* names, const int64_t* name_off,
+                                    const int64_t* row_ptr, const int32_t* col, int threads) {
+    if (!path || n < 0 || (n > 0 && (!names || !name_off || !row_ptr)) || (n > 0 && row_ptr[n] > 0 && !col)) {
+        sdice_set_error("sdice_write_clusters: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    FILE* fh = fopen(path, "wb");
+    if (!fh) {
+        sdice_set_error("sdice_write_clusters: cannot open %s", path);
+        return SDICE_ERR_ARG;
+    }
+    const int64_t block = 1 << 16;
+    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    std::vector<std::string> bufs;
+    for (int64_t r0 = 0; r0 < n; r0 += block) {
+        const int64_t nb = std::min(block, n - r0);
+        int used = nb < 4096 ? 1 : std::min(nthreads, 64);
+        if (used < 1) used = 1;
+        bufs.assign(used, std::string());
+        bool bad = false;
+        parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
+            std::string& out = bufs[t];
+            for (int64_t r = r0 + a; r < r0 + b; ++r) {
+                out.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+                out += '\t';
+                for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+                    const int64_t c = col[k];
+                    if (c < 0 || c >= n) { bad = true; continue; }
+                    if (k > row_ptr[r]) out += ',';
+                    out.append(names + name_off[c], (size_t)(name_off[c + 1] - name_off[c]));
+                }
+                out += '\n';
+            }
+        });
+        if (bad) {
+            fclose(fh);
+            sdice_set_error("sdice_write_clusters: col index out of range");
+            return SDICE_ERR_ARG;
+        }
+        for (auto& b : bufs)
+            if (!b.empty() && fwrite(b.data(), 1, b.size(), fh) != b.size()) {
+                fclose(fh);
+                sdice_set_error("sdice_write_clusters: short write to %s", path);
+                return SDICE_ERR_ARG;
+            }
+    }
+    if (fclose(fh) != 0) {
+        sdice_set_error("sdice_write_clusters: close failed for %s", path);
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ reader
 struct sdice_table {
     int fd = -1;

@@ -219,6 +219,13 @@ class Context:
         check(self.lib.sdice_bh_columns(self.h, n, cols, _ptr(out)), "sdice_bh_columns")
         return out
 
+    def sort_unique_u64(self, keys):
+        """sorted distinct 64-bit keys (the junction union of quant, SPLICEDICE.py:147-228 + :96)"""
+        keys = np.array(keys, dtype=np.uint64, order="C", copy=True)
+        n_unique = C.c_int64()
+        check(self.lib.sdice_sort_unique_u64(self.h, keys.size, _ptr(keys), C.byref(n_unique)), "sdice_sort_unique_u64")
+        return keys[: n_unique.value]
+
     def similarity(self, ps, mid, sign):
         """similarity.py:25-47 -> (scores int64[s], counts int64[s]); ps float64 [n, s]"""
         ps, mid, sign = _c(ps, np.float64), _c(mid, np.float64), _c(sign, np.int8)

@@ -57,9 +57,36 @@ def lookup_rows(rows, q_chrom, q_left, q_right, q_strand):
     return out
 
 
-def ingest(manifest, args):
+# order-preserving 64-bit packing of (chrom_rank, left, right, strand): 12 | 31 | 20 | 1 bits
+_SPAN_BITS, _LEFT_BITS, _CHROM_BITS = 20, 31, 12
+
+
+def _union_packed(ctx, recs):
+    """Sorted junction union through sdice_sort_unique_u64, or None when a junction does not fit the
+    packing (more than 4096 chromosomes, span >= 2^20, negative coordinates)."""
+    parts = []
+    for rec in recs:
+        a = rec["admit"].astype(bool)
+        if not a.any():
+            continue
+        c, l, r = rec["chrom_rank"][a].astype(np.int64), rec["left"][a].astype(np.int64), rec["right"][a].astype(np.int64)
+        span = r - l
+        if c.max() >= 1 << _CHROM_BITS or l.min() < 0 or span.min() < 0 or span.max() >= 1 << _SPAN_BITS:
+            return None
+        parts.append(((c << (_LEFT_BITS + _SPAN_BITS + 1)) | (l << (_SPAN_BITS + 1)) | (span << 1)
+                      | rec["strand"][a].astype(np.int64)).astype(np.uint64))
+    if not parts:
+        return tuple(np.zeros(0, d) for d in (np.int32, np.int32, np.int32, np.int8))
+    keys = ctx.sort_unique_u64(np.concatenate(parts)).astype(np.int64)
+    left = (keys >> (_SPAN_BITS + 1)) & ((1 << _LEFT_BITS) - 1)
+    return ((keys >> (_LEFT_BITS + _SPAN_BITS + 1)).astype(np.int32), left.astype(np.int32),
+            (left + ((keys >> 1) & ((1 << _SPAN_BITS) - 1))).astype(np.int32), (keys & 1).astype(np.int8))
+
+
+def ingest(manifest, args, ctx=None):
     """All sample files of a manifest -> (chrom_names_sorted, junction arrays in row order
-    (chrom_rank, left, right, strand), parsed per-sample records with global chromosome ranks)."""
+    (chrom_rank, left, right, strand), parsed per-sample records with global chromosome ranks).
+    With an engine context the union / sort of the junction set runs on the GPU."""
     parsed = []
     all_names = set()
     for sample in manifest:
@@ -76,6 +103,13 @@ def ingest(manifest, args):
             continue
         local = np.fromiter((rank[c] for c in rec["chroms"]), dtype=np.int32, count=len(rec["chroms"]))
         rec["chrom_rank"] = local[rec["chrom_id"]] if rec["chrom_id"].size else np.zeros(0, np.int32)
+    if ctx is not None:
+        junc = _union_packed(ctx, [rec for rec in parsed if rec is not None])
+        if junc is not None:
+            return names, junc, parsed
+    for rec in parsed:
+        if rec is None:
+            continue
         a = rec["admit"].astype(bool)
         if a.any():
             k1 = (rec["chrom_rank"][a].astype(np.int64) << 32) | rec["left"][a].astype(np.int64)

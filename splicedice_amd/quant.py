@@ -183,7 +183,7 @@ class Quant:
         print(f"Getting all junctions from {len(self.manifest)} files...")
         # one multithreaded pass per file (csrc/juncio.cpp) instead of the reference's two Python
         # passes; get_all_junctions / get_junction_counts below state the same rules in Python
-        chrom_names, junc, parsed = juncio.ingest(self.manifest, self.args)
+        chrom_names, junc, parsed = juncio.ingest(self.manifest, self.args, self.ctx)
         print("\tDone", timer.check())
 
         print(f"Finding clusters from {junc[0].size} junctions...")
@@ -237,10 +237,7 @@ class Quant:
                 out.write(f"{j[0]}\t{j[1]}\t{j[2]}\t{name}\t0\t{j[3]}\n")
 
     def write_clusters(self):
-        names, rp, col = self.names, self.row_ptr, self.col
-        with open(f"{self.outputPrefix}_allClusters.tsv", "w") as out:
-            for r, name in enumerate(names):
-                out.write(name + "\t" + ",".join(names[c] for c in col[rp[r]:rp[r + 1]]) + "\n")
+        textio.write_clusters(f"{self.outputPrefix}_allClusters.tsv", self.names, self.row_ptr, self.col)
 
     def _sample_header(self, first):
         return first + "\t" + "\t".join(s.name for s in self.manifest) + "\n"

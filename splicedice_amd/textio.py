@@ -81,6 +81,51 @@ def write_table(path, header, names, data, mode, threads=0):
     _ffi.check(rc, "sdice_write_table")
 
 
+def write_columns(path, header, names, columns, modes, threads=0):
+    """Like write_table for column-major data: `columns` is a list of 1-D arrays (float32 / float64
+    / int32, one value per row), `modes` one of '.3f' | '.0f' | 'repr' per column
+    (sdice_write_columns)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    n = len(names)
+    cols = [np.ascontiguousarray(c) for c in columns]
+    for c in cols:
+        if c.dtype not in _DTYPE_CODE or c.shape != (n,):
+            raise TypeError(f"write_columns: unsupported column {c.dtype} {c.shape}")
+    blobs = [str(nm).encode() for nm in names]
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum([len(b) for b in blobs], out=off[1:])
+    blob = b"".join(blobs)
+    ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    dts = np.array([_DTYPE_CODE[c.dtype] for c in cols], dtype=np.int32)
+    mds = np.array([_MODE_CODE[m] for m in modes], dtype=np.int32)
+    rc = lib.sdice_write_columns(str(path).encode(), header.encode(), n, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
+                                 len(cols), ptrs, dts.ctypes.data_as(C.c_void_p), mds.ctypes.data_as(C.c_void_p),
+                                 int(threads))
+    _ffi.check(rc, "sdice_write_columns")
+
+
+def write_clusters(path, names, row_ptr, col, threads=0):
+    """`_allClusters.tsv`: name<TAB>comma-joined neighbour names per row (sdice_write_clusters)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    n = len(names)
+    blobs = [str(nm).encode() for nm in names]
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum([len(b) for b in blobs], out=off[1:])
+    blob = b"".join(blobs)
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    cl = np.ascontiguousarray(col, dtype=np.int32)
+    assert rp.size == n + 1
+    rc = lib.sdice_write_clusters(str(path).encode(), n, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
+                                  rp.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p), int(threads))
+    _ffi.check(rc, "sdice_write_clusters")
+
+
 def read_table_numeric(path, dtype=np.float32, threads=0):
     """-> (header_line, names list, data[n, s]) through the library's mmap + multithreaded parser
     (numpy semantics: text -> float64 -> dtype)."""

@@ -418,3 +418,37 @@ def test_bh_columns_batched(ctx, n, cols):
     d = ctx.to_device(p)
     ctx.bh_columns_dev(d)
     np.testing.assert_allclose(d.to_host(), O.bh_columns(p), rtol=1e-14, atol=0)
+
+
+# ------------------------------------------------------------------------------ junction union
+@pytest.mark.parametrize("n,distinct", [(1, 1), (2, 1), (5000, 40), (300_000, 90_000), (1_000_000, 1_000_000)])
+def test_sort_unique_u64(ctx, n, distinct):
+    rng = np.random.default_rng(n + distinct)
+    pool = rng.integers(0, 1 << 63, size=distinct, dtype=np.uint64) | (rng.integers(0, 2, size=distinct, dtype=np.uint64) << np.uint64(63))
+    keys = pool[rng.integers(0, distinct, size=n)]
+    got = ctx.sort_unique_u64(keys)
+    assert np.array_equal(got, np.unique(keys))
+    assert ctx.sort_unique_u64(np.zeros(0, np.uint64)).size == 0
+    same = ctx.sort_unique_u64(np.full(777, 12345, np.uint64))
+    assert same.tolist() == [12345]
+
+
+def test_ingest_union_gpu_equals_host(ctx, golden_dir):
+    """juncio.ingest with the engine (packed keys, GPU sort + unique) == the numpy path."""
+    from splicedice_amd import juncio, quant
+    import argparse
+    qdir = os.path.join(golden_dir, "quant_c1")
+    p = argparse.ArgumentParser()
+    quant.add_parser(p)
+    args = p.parse_args(["-m", os.path.join(qdir, "manifest.rel.tsv"), "-o", "x"])
+    cwd = os.getcwd()
+    os.chdir(os.path.join(qdir, "inputs"))
+    try:
+        manifest = quant.parse_manifest(args.manifest)
+        a = juncio.ingest(manifest, args, ctx)
+        b = juncio.ingest(manifest, args, None)
+    finally:
+        os.chdir(cwd)
+    assert a[0] == b[0] and a[1][0].size > 500
+    for x, y in zip(a[1], b[1]):
+        assert x.dtype == y.dtype and np.array_equal(x, y)

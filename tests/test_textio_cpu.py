@@ -172,3 +172,38 @@ def test_junction_parser_edge_cases(tmp_path):
     rows = (np.int32([0, 0, 1]), np.int32([5, 5, 1]), np.int32([9, 9, 2]), np.int8([0, 1, 0]))
     got = juncio.lookup_rows(rows, [0, 1, 0, 2], [5, 1, 5, 1], [9, 2, 8, 2], [1, 0, 0, 0])
     assert got.tolist() == [1, 2, -1, -1]
+
+
+def test_write_columns_mixed_dtypes(tmp_path):
+    """column-major writer: float32 and float64 numpy-repr columns side by side == print(*fields, sep='\\t')"""
+    from splicedice_amd import textio
+    rng = np.random.default_rng(12)
+    n = 5000
+    a = rng.random(n).astype(np.float32)
+    b = (rng.random(n) * 1e-9)
+    c = rng.integers(0, 1000, n).astype(np.int32)
+    a[:4] = np.float32([0.17800002, 1.0, 0.0, 1e-5])
+    b[:4] = [0.376759117811582, 1.0, 4.9817526009363926e-11, 0.0]
+    names = [f"chr1:{i}-{i + 7}:+" for i in range(n)]
+    path = str(tmp_path / "cols.tsv")
+    textio.write_columns(path, "h\tx\ty\tz\n", names, [a, b, c], ["repr", "repr", ".0f"])
+    want = "h\tx\ty\tz\n" + "".join(f"{names[i]}\t{str(a[i])}\t{str(b[i])}\t{c[i]}\n" for i in range(n))
+    assert open(path).read() == want
+    textio.write_columns(path, "h\n", [], [], [])
+    assert open(path).read() == "h\n"
+
+
+def test_write_clusters(tmp_path):
+    from splicedice_amd import textio
+    names = [f"chr1:{i}-{i + 9}:-" for i in range(6000)]
+    rng = np.random.default_rng(3)
+    deg = rng.integers(0, 5, size=6000)
+    deg[0] = 0
+    rp = np.r_[0, np.cumsum(deg)].astype(np.int64)
+    col = rng.integers(0, 6000, size=int(rp[-1])).astype(np.int32)
+    path = str(tmp_path / "cl.tsv")
+    textio.write_clusters(path, names, rp, col)
+    want = "".join(names[r] + "\t" + ",".join(names[c] for c in col[rp[r]:rp[r + 1]]) + "\n" for r in range(6000))
+    assert open(path).read() == want
+    textio.write_clusters(path, [], np.zeros(1, np.int64), np.zeros(0, np.int32))
+    assert open(path).read() == ""
