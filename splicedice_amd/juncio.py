@@ -18,7 +18,7 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def parse_sample(path, type_code, args):
+def parse_sample(path, type_code, args, threads=0):
     """-> dict(chroms list[str], chrom_id i32[n], left i32[n], right i32[n], strand i8[n] (0 '+', 1 '-', 2 other),
     score i64[n], admit u8[n])"""
     lib = _ffi.load()
@@ -35,7 +35,7 @@ def parse_sample(path, type_code, args):
         rc = lib.sdice_junc_read(h, int(args.minLength), int(args.maxLength), int(args.minUnique), int(args.minOverhang),
                                  float(args.minEntropy), 1 if args.noMultimap else 0, _vp(out["chrom_id"]),
                                  _vp(out["left"]), _vp(out["right"]), _vp(out["strand"]), _vp(out["score"]),
-                                 _vp(out["admit"]), names, _vp(off), 0)
+                                 _vp(out["admit"]), names, _vp(off), int(threads))
         if rc != 0:
             raise ValueError(f"{path}: {lib.sdice_last_error().decode()}")
     finally:
@@ -87,12 +87,24 @@ def ingest(manifest, args, ctx=None):
     """All sample files of a manifest -> (chrom_names_sorted, junction arrays in row order
     (chrom_rank, left, right, strand), parsed per-sample records with global chromosome ranks).
     With an engine context the union / sort of the junction set runs on the GPU."""
-    parsed = []
-    all_names = set()
-    for sample in manifest:
+    # the files are parsed concurrently (the library call releases the GIL); results keep manifest order
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(len(manifest), cores, 16))
+    per_file = max(1, cores // workers)
+
+    def _one(sample):
         code = TYPE_CODE.get(sample.type)
-        rec = parse_sample(sample.filename, code, args) if code is not None else None
-        parsed.append(rec)
+        return parse_sample(sample.filename, code, args, per_file) if code is not None else None
+
+    if workers > 1:
+        with ThreadPoolExecutor(workers) as pool:
+            parsed = list(pool.map(_one, manifest))
+    else:
+        parsed = [_one(sample) for sample in manifest]
+    all_names = set()
+    for rec in parsed:
         if rec is not None:
             all_names.update(rec["chroms"])
     names = sorted(all_names)                     # Python string order, as the reference's tuple sorts
