@@ -431,6 +431,25 @@ def cpu_baseline_all_cores(workload):
         return {"value": None, "cores": cores, "error": str(e)[:200]}
 
 
+def reference_over_port(workload):
+    """Speed of the REAL reference relative to the port timed here, measured in the build container
+    where the reference is importable (tests/golden/time_reference.py -> profiles/reference_in_container.json):
+    the port is a little slower than the code it restates, so GPU/port ratios overstate GPU/reference by this factor."""
+    try:
+        with open(os.path.join(REPO, "profiles", "reference_in_container.json")) as fh:
+            d = json.load(fh)
+        if workload in ("quant", "e2e"):
+            q = d["quant_100k_x_100"]
+            return round(q["reference"]["entries_per_s"] / q["oracle_port"]["entries_per_s"], 2)
+        if workload == "compare":
+            c = d["compare_20k_rows_50v50"]
+            return round(c["reference_loop_rows_per_s"] / c["oracle_port_rows_per_s"], 2)
+        f = [v for k, v in d.items() if k.startswith("pairwise_fisher")][0]
+        return round(f["reference_loop_p_per_s"] / f["oracle_port_p_per_s"], 2)
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def main():
     args = parse_args()
     all_cores = None
@@ -498,6 +517,7 @@ def main():
     if dist.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = wl.cpu_baseline(args.cpu_sample)
         cpu["all_cores"] = all_cores
+        cpu["real_reference_over_port"] = reference_over_port(args.workload)
 
     if dist.rank == 0:
         total_units = wl.units * args.gpus * args.steps
