@@ -27,6 +27,18 @@ __device__ __forceinline__ double logfact(const LfTable& t, long long k) {
     return k < t.n ? t.lf[k] : lgamma((double)k + 1.0);
 }
 
+// 1/y for y an integer-valued double in [1, 2^63): hardware seed + two Newton steps (no scaling or
+// fix-up is ever needed in this range).  Accurate to ~1 ulp; the step ratios it feeds carry a
+// relative error of a few 1e-16, against a tie slack of 1e-12 and a p-value tolerance of 1e-9.
+// The IEEE division it replaces was ~2/3 of the instructions of a walk step.
+__device__ __forceinline__ double rcp_pos(double y) {
+    double x = __builtin_amdgcn_rcp(y);
+    double e = fma(-y, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-y, x, 1.0);
+    return fma(x, e, x);
+}
+
 // one-directional walk of the ratios; dir = +1 (k increasing) or -1
 template <int DIR>
 __device__ __forceinline__ double walk_side(double a, double n1, double n2, double n, double bound_steps) {
@@ -39,7 +51,7 @@ __device__ __forceinline__ double walk_side(double a, double n1, double n2, doub
     double r = 1.0, total = 0.0;
     int e = 0;   // r is scaled by 2^(500 e) while it is astronomically above 1
     for (double t = 0.0; t < bound_steps; t += 1.0) {
-        const double rho = (u1 * u2) / (v1 * v2);
+        const double rho = (u1 * u2) * rcp_pos(v1 * v2);
         r *= rho;
         u1 -= 1.0; u2 -= 1.0; v1 += 1.0; v2 += 1.0;
         if (r > 0x1p500) { r *= 0x1p-500; ++e; }
