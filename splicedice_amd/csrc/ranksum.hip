@@ -362,9 +362,11 @@ __device__ int block_compact(const float* __restrict__ prow, const int32_t* __re
 }
 
 // numpy's pairwise_sum recursion  `n <= 128 ? leaf : sum(a, n2) + sum(a + n2, n - n2)`,
-// n2 = n/2 - (n/2) % 8, unrolled at compile time to PW_DEPTH levels (n <= 128 << PW_DEPTH).  Every
-// thread walks it redundantly with block-uniform arguments: no stacks, no single-lane section.
-constexpr int PW_DEPTH = 5;
+// n2 = n/2 - (n/2) % 8, unrolled at compile time to PW_DEPTH levels.  The larger half is up to
+// len/2 + 7.5, so 4096 values can need SIX levels (4095 -> 2055 -> 1031 -> 519 -> 263 -> 135 -> 71)
+// and up to 64 leaves.  Every thread walks it redundantly with block-uniform arguments: no stacks,
+// no single-lane section.
+constexpr int PW_DEPTH = 6;
 
 template <int DEPTH>
 __device__ __forceinline__ void pw_leaves(int off, int len, int* leaf_off, int& nl, bool writer) {
@@ -564,31 +566,38 @@ __device__ __forceinline__ void bitonic_wave(float (&a)[E], int lane) {
     }
 }
 
-// numpy pairwise_sum of C[0..nv) (nv <= 1024: at most 8 leaves) by one wave: lane = leaf*8 + j
-// owns accumulator j of its leaf; the 8 accumulators are folded with three xor-exchanges, which
-// reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) because float addition is commutative.
+// numpy pairwise_sum of C[0..nv) (nv <= 1024) by one wave: lane = leaf*8 + j owns accumulator j
+// of its leaf; the 8 accumulators are folded with three xor-exchanges, which reproduces
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) because float addition is commutative.  The halving keeps
+// multiples of 8 on the left, so the larger half is up to len/2 + 7.5: 1024 values need up to FOUR
+// levels (e.g. 972 -> 492 -> 252 -> 132 -> 68) and up to 16 leaves -- two rounds of 8 leaves.
+constexpr int PW_WAVE_DEPTH = 4;
+
 __device__ __forceinline__ float wave_pairwise_sum(const float* C, int nv, int lane, int* leaf_off, float* leaf_sum) {
     int nl = 0;
-    pw_leaves<3>(0, nv, leaf_off, nl, lane == 0);
+    pw_leaves<PW_WAVE_DEPTH>(0, nv, leaf_off, nl, lane == 0);
     if (lane == 0) leaf_off[nl] = nv;
     SD_WAVE_SYNC();
-    const int L = lane >> 3, j = lane & 7;
-    int off = 0, len = 0;
-    if (L < nl) { off = leaf_off[L]; len = leaf_off[L + 1] - off; }
-    const int main_n = len - (len & 7);
-    float r = 0.f;
-    if (len >= 8) {
-        r = C[off + j];
-        for (int i = 8; i < main_n; i += 8) r += C[off + i + j];
+    const int j = lane & 7;
+    for (int base = 0; base < nl; base += 8) {          // wave-uniform trip count
+        const int L = base + (lane >> 3);
+        int off = 0, len = 0;
+        if (L < nl) { off = leaf_off[L]; len = leaf_off[L + 1] - off; }
+        const int main_n = len - (len & 7);
+        float r = 0.f;
+        if (len >= 8) {
+            r = C[off + j];
+            for (int i = 8; i < main_n; i += 8) r += C[off + i + j];
+        }
+        r = r + __shfl_xor(r, 1);
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        for (int i = (len >= 8 ? main_n : 0); i < len; ++i) r += C[off + i];
+        if (j == 0 && L < nl) leaf_sum[L] = r;
     }
-    r = r + __shfl_xor(r, 1);
-    r = r + __shfl_xor(r, 2);
-    r = r + __shfl_xor(r, 4);
-    for (int i = (len >= 8 ? main_n : 0); i < len; ++i) r += C[off + i];
-    if (j == 0 && L < nl) leaf_sum[L] = r;
     SD_WAVE_SYNC();
     int next = 0;
-    const float out = pw_combine<3>(nv, leaf_sum, next);
+    const float out = pw_combine<PW_WAVE_DEPTH>(nv, leaf_sum, next);
     SD_WAVE_SYNC();
     return out;
 }
@@ -600,13 +609,13 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
                                                            RsOut o) {
     extern __shared__ __align__(16) float smemw[];
     constexpr int N = 64 * E;
-    constexpr int WSTRIDE = 2 * N + 32;
+    constexpr int WSTRIDE = 2 * N + 40;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     float* SA = smemw + (size_t)wave * WSTRIDE;
     float* SB = SA + N;
-    float* leaf_sum = SB + N;                                  // [<= 9]
-    int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);     // [<= 10]
+    float* leaf_sum = SB + N;                                  // [<= 16]
+    int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);     // [<= 17]
     const float inf = __builtin_inff();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // the selected columns of this lane (striped: selection k = e*64 + lane), loaded once
@@ -739,7 +748,7 @@ template <int E>
 int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* g1, int n1, const int32_t* g2,
                 int n2, RsOut o) {
     const int waves = 4;
-    const size_t lds = (size_t)waves * (2 * 64 * E + 32) * 4;
+    const size_t lds = (size_t)waves * (2 * 64 * E + 40) * 4;
     // rows per chunk: as many as keeps every wave slot of the chip (32 per CU) busy twice over
     const int64_t slots = (int64_t)ctx->n_cu * 32;
     int ch = 64;
@@ -849,8 +858,8 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         }
     }
     const int P1 = next_pow2(n1), P2 = next_pow2(n2);
-    SD_ARG(big <= (128 << 5), "group larger than 4096 samples is not supported");
-    const int leaf_max = 36;             // <= 2^5 leaves of numpy's pairwise recursion (+ sentinel)
+    SD_ARG(big <= 4096, "group larger than 4096 samples is not supported");
+    const int leaf_max = 72;             // <= 2^6 leaves of numpy's pairwise recursion (+ sentinel)
     const size_t lds = (size_t)(P1 + P2 + leaf_max * 9) * 4 + (size_t)(leaf_max + 1 + 8) * 4;
     SD_ARG(lds <= 150 * 1024, "groups too large for LDS");
     int64_t blocks = n;

@@ -452,3 +452,29 @@ def test_ingest_union_gpu_equals_host(ctx, golden_dir):
     assert a[0] == b[0] and a[1][0].size > 500
     for x, y in zip(a[1], b[1]):
         assert x.dtype == y.dtype and np.array_equal(x, y)
+
+
+def test_ranksum_fuzz_shapes(ctx):
+    """random group sizes across the kernel boundaries (pair <= 64 < wave <= 1024 < block), random NaN
+    density, ties from 3-decimal quantisation; every variant that accepts the shape must agree with the oracle"""
+    rng = np.random.default_rng(2024)
+    sizes = [(3, 64), (64, 65), (65, 65), (5, 1024), (1025, 4), (127, 129), (33, 31), (256, 255), (513, 40),
+             (4095, 5), (1000, 24), (700, 900), (2049, 2049), (263, 135)]       # incl. pairwise-sum depths 4 and 6
+    for n1, n2 in sizes:
+        s = n1 + n2 + int(rng.integers(0, 7))
+        n = 97
+        ps = synth.make_ps_matrix(n, s, seed=n1 * 7 + n2, nan_frac=float(rng.choice([0.0, 0.05, 0.5])))
+        ps[3, :] = np.nan
+        ps[4, :] = 1.0
+        cols = rng.permutation(s)
+        g1, g2 = np.sort(cols[:n1]), np.sort(cols[n1:n1 + n2])
+        want = O.compare_rows(ps, g1, g2)
+        big = max(n1, n2)
+        variants = [0, 2] + ([1, 4] if big <= 64 else []) + ([3] if big <= 1024 else [])
+        for variant in variants:
+            ctx.set_param("ranksum.variant", variant)
+            try:
+                got = ctx.ranksum(ps, g1, g2)
+            finally:
+                ctx.set_param("ranksum.variant", 0)
+            _check_ranksum(got, want)
