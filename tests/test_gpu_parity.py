@@ -478,3 +478,67 @@ def test_ranksum_fuzz_shapes(ctx):
             finally:
                 ctx.set_param("ranksum.variant", 0)
             _check_ranksum(got, want)
+
+
+# ------------------------------------------------------------------------------ shape fuzz
+def test_ps_fuzz_shapes(ctx):
+    """random (n, s) incl. s not a multiple of 4, chunk boundaries around 256/128, heavy rows, far
+    neighbours, count magnitudes across the 2^24 switch; PS and exclusion sums vs the oracle."""
+    rng = np.random.default_rng(4242)
+    shapes = [(1, 1), (2, 3), (37, 5), (500, 127), (500, 129), (300, 255), (300, 257), (200, 260), (150, 385),
+              (64, 513), (900, 100), (400, 12), (90, 1030)]
+    for n, s in shapes:
+        deg = rng.integers(0, 9, size=n)
+        if n > 20:
+            deg[rng.integers(0, n, size=3)] = rng.integers(17, min(n, 60) + 1, size=3)     # heavy rows
+        row_ptr = np.r_[0, np.cumsum(deg)].astype(np.int64)
+        near = np.repeat(np.arange(n), deg) + rng.integers(-6, 7, size=int(row_ptr[-1]))
+        far = rng.integers(0, n, size=near.size)
+        col = np.clip(np.where(rng.random(near.size) < 0.9, near, far), 0, n - 1).astype(np.int32)
+        scale = int(rng.choice([1, 1, 1000, 200000]))
+        counts = (synth.make_counts(n, s, seed=n * 31 + s).astype(np.int64) * scale).clip(0, (1 << 24) - 1).astype(np.int32)
+        want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+        ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+        assert np.array_equal(excl, want_excl), (n, s, scale)
+        assert np.array_equal(ps, want_ps, equal_nan=True), (n, s, scale)
+
+
+def test_fisher_fuzz_tables(ctx):
+    """random 2x2 tables over many magnitudes incl. zero margins, a at either end of the support, and
+    large balanced tables (mathematical ties across the mode); vs scipy through the oracle"""
+    from scipy.stats import fisher_exact
+    rng = np.random.default_rng(99)
+    tabs = []
+    for mag in (3, 30, 300, 3000, 100000):
+        t = rng.integers(0, mag, size=(60, 4))
+        t[rng.random(60) < 0.15, rng.integers(0, 4)] = 0
+        tabs.append(t)
+    sym = np.array([[k, m - k, m - k, k] for m in (10, 101, 1000, 5000) for k in (0, 1, m // 3, m // 2, m)])
+    tabs.append(sym)
+    tables = np.concatenate(tabs).astype(np.int64)
+    want = np.array([fisher_exact([[a, b], [c, d]])[1] for a, b, c, d in tables])
+    got = ctx.fisher_tables(tables)
+    # margins of ~1e5: pmf(a) = exp(sum of nine log-factorials of size ~1e6) -- both scipy's and this
+    # evaluation carry ~1e-9 relative error there; everything smaller agrees to 1e-9
+    big = tables.sum(axis=1) > 50_000
+    np.testing.assert_allclose(got[~big], want[~big], rtol=P_RTOL_TIGHT, atol=0)
+    np.testing.assert_allclose(got[big], want[big], rtol=1e-7, atol=0)
+
+
+def test_cluster_fuzz(ctx):
+    """random junction sets: tiny, one chromosome, identical coordinates on both strands, heavy overlap"""
+    rng = np.random.default_rng(31337)
+    for n, n_chrom, span in [(1, 1, 10), (2, 1, 10), (3, 2, 1000), (400, 1, 300), (700, 5, 50), (1500, 2, 20000)]:
+        cr = rng.integers(0, n_chrom, size=n).astype(np.int32)
+        left = rng.integers(0, 5000, size=n).astype(np.int32)
+        right = (left + rng.integers(1, span + 1, size=n)).astype(np.int32)
+        strand = rng.integers(0, 2, size=n).astype(np.int8)
+        key = np.unique(np.stack([cr, left, right, strand], axis=1), axis=0)      # the reference holds a SET
+        cr, left, right, strand = (key[:, 0].astype(np.int32), key[:, 1].astype(np.int32), key[:, 2].astype(np.int32),
+                                   key[:, 3].astype(np.int8))
+        perm = rng.permutation(cr.size)
+        cr, left, right, strand = cr[perm], left[perm], right[perm], strand[perm]
+        want = O.cluster_csr(cr, left, right, strand)
+        got = ctx.cluster(cr, left, right, strand)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), (n, n_chrom, span)
