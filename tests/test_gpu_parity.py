@@ -542,3 +542,20 @@ def test_cluster_fuzz(ctx):
         got = ctx.cluster(cr, left, right, strand)
         for g, w in zip(got, want):
             assert np.array_equal(g, w), (n, n_chrom, span)
+
+
+def test_bh_fuzz(ctx):
+    """vector and per-column BH over awkward sizes (1, 2, tile boundaries of the radix sort), heavy ties,
+    all ones, denormal-small p-values"""
+    rng = np.random.default_rng(515)
+    for m in (1, 2, 3, 255, 256, 257, 3071, 3072, 3073, 6145, 40_000):
+        p = rng.random(m) ** rng.choice([1, 4, 30])
+        p[rng.random(m) < 0.3] = 1.0
+        if m > 10:
+            p[:5] = [0.0, 5e-324, 1e-300, 1.0, 0.5]
+            p[5:10] = p[10]                      # exact ties
+        np.testing.assert_allclose(ctx.bh(p), O.bh_fdr(p), rtol=1e-14, atol=0)
+    for n, cols in ((1, 1), (1, 7), (2, 3), (257, 2), (3073, 5), (50, 300), (700, 33)):
+        p = rng.random((n, cols)) ** 3
+        p[rng.random((n, cols)) < 0.2] = 1.0
+        np.testing.assert_allclose(ctx.bh_columns(p), O.bh_columns(p), rtol=1e-14, atol=0)
