@@ -1,80 +1,81 @@
 """`splicedice similarity` on the MI355X engine.
 
 Scores every sample of an `_allPS.tsv` table against the significant events of a
-compare_sample_sets output (reference: splicedice/similarity.py).  Host side mirrors the
-reference's reading rules; the per-sample counting over the PS matrix runs in the HIP kernel
-`similarity_kernel` (sdice_similarity).
+compare_sample_sets output.  The per-sample counting over the PS matrix runs in the HIP kernel
+`similarity_kernel` (sdice_similarity); this module is the host side and keeps the reference's
+reading and writing rules (splicedice/similarity.py, line numbers below):
 
-  * comparison table (similarity.py:5-21): header skipped; a row is used when float(p-value) is
-    not > 0.05 and delta != 0; midpoint = median1 - delta/2 (Python floats of the text fields).
-  * allps table (:24-47): rows whose name is not in the comparison are ignored; "nan" fields do
-    not count; delta < 0 scores ps < midpoint, delta > 0 scores ps > midpoint.
-  * output (:57-66): lines sorted by (score, sample, count) descending;
-    sample[<TAB>group1<TAB>group2]<TAB>{score/count:0.03f}<TAB>score<TAB>count; with a manifest
-    only samples named in it are written.  A sample with count 0 raises ZeroDivisionError as
-    the reference does.
+  comparison table (:5-21)  first line skipped; an event is used unless float(p-value) > 0.05 or
+                            delta == 0; its midpoint is median1 - delta/2 on Python floats of the text
+  PS table (:24-47)         events absent from the comparison are ignored, "nan" fields do not count;
+                            delta < 0 scores ps < midpoint, delta > 0 scores ps > midpoint
+  output (:57-66)           samples ordered by (score, name, count) descending; one line
+                            name[<TAB>group1<TAB>group2]<TAB>score/count as 0.03f<TAB>score<TAB>count;
+                            with a manifest only the samples it names; count == 0 raises
+                            ZeroDivisionError exactly as the reference does
 """
 import numpy as np
 
 from . import textio
 from .engine import Context
 
+P_CUTOFF = 0.05
+COL_MEDIAN1, COL_DELTA, COL_P = 3, 5, 6
 
-def read_vs_file(vs_filename):
-    """similarity.py:5-21 -> (midpoints dict, deltas dict)"""
-    midpoints, deltas = {}, {}
-    with open(vs_filename) as vs_file:
-        vs_file.readline()
-        for line in vs_file:
-            row = line.rstrip().split("\t")
-            if float(row[6]) > 0.05:
+
+def significant_events(comparison_path):
+    """-> {event: (midpoint, delta)} for the rows of a compare_sample_sets table that pass the cut-off"""
+    events = {}
+    with open(comparison_path) as table:
+        next(table, None)
+        for record in table:
+            cells = record.rstrip().split("\t")
+            delta = float(cells[COL_DELTA])
+            if float(cells[COL_P]) > P_CUTOFF or delta == 0:
                 continue
-            delta = float(row[5])
-            if delta == 0:
-                continue
-            midpoints[row[0]] = float(row[3]) - (delta / 2)
-            deltas[row[0]] = delta
-    return midpoints, deltas
+            events[cells[0]] = (float(cells[COL_MEDIAN1]) - delta / 2, delta)
+    return events
 
 
-def row_parameters(names, midpoints, deltas):
-    """Per table row: midpoint (float64) and sign of delta (int8; 0 = row not scored)."""
+def row_parameters(names, events):
+    """Per PS-table row: midpoint (float64) and sign of delta (int8; 0 = row is not scored)."""
     mid = np.zeros(len(names), dtype=np.float64)
     sign = np.zeros(len(names), dtype=np.int8)
     for i, name in enumerate(names):
-        d = deltas.get(name)
-        if d is not None:
-            mid[i] = midpoints[name]
-            sign[i] = -1 if d < 0 else 1
+        hit = events.get(name)
+        if hit is not None:
+            mid[i] = hit[0]
+            sign[i] = 1 if hit[1] > 0 else -1
     return mid, sign
 
 
-def score_samples(ctx, allps_filename, midpoints, deltas):
-    """similarity.py:24-47 -> (samples, scores, counts)"""
-    header, names, ps = textio.read_table_numeric(allps_filename, dtype=np.float64)
-    samples = header.rstrip().split("\t")[1:]
-    mid, sign = row_parameters(names, midpoints, deltas)
+def score_table(ctx, allps_path, events):
+    """-> (sample names, scores, counts) -- the PS matrix is parsed as float64 by the library's reader
+    and scored on the GPU"""
+    header, names, ps = textio.read_table_numeric(allps_path, dtype=np.float64)
+    mid, sign = row_parameters(names, events)
     scores, counts = ctx.similarity(ps, mid, sign)
-    return samples, [int(x) for x in scores], [int(x) for x in counts]
+    return header.rstrip().split("\t")[1:], scores.tolist(), counts.tolist()
 
 
-def get_groups(manifest_filename):
-    groups = {}
-    with open(manifest_filename) as manifest:
-        for line in manifest:
-            name, path, group1, group2 = line.rstrip().split("\t")
-            groups[name] = (group1, group2)
-    return groups
+def sample_groups(manifest_path):
+    with open(manifest_path) as manifest:
+        rows = (line.rstrip().split("\t") for line in manifest)
+        return {name: (g1, g2) for name, _path, g1, g2 in rows}
 
 
-def write_scores(output_filename, scores, samples, counts, groups=None):
-    with open(output_filename, "w") as score_file:
-        for score, sample, count in sorted(zip(scores, samples, counts), reverse=True):
-            if groups and sample in groups:
-                group1, group2 = groups[sample]
-                score_file.write(f"{sample}\t{group1}\t{group2}\t{score / count:0.03f}\t{score}\t{count}\n")
-            elif not groups:
-                score_file.write(f"{sample}\t{score / count:0.03f}\t{score}\t{count}\n")
+def write_report(path, samples, scores, counts, groups=None):
+    ranking = sorted(range(len(samples)), key=lambda i: (scores[i], samples[i], counts[i]), reverse=True)
+    with open(path, "w") as out:
+        for i in ranking:
+            name, score, count = samples[i], scores[i], counts[i]
+            if groups:
+                if name not in groups:
+                    continue
+                label = "\t".join((name,) + tuple(groups[name]))
+            else:
+                label = name
+            out.write(f"{label}\t{score / count:0.03f}\t{score}\t{count}\n")
 
 
 def add_parser(parser):
@@ -88,7 +89,6 @@ def add_parser(parser):
 
 def run_with(args, ctx=None):
     ctx = ctx if ctx is not None else Context(0)
-    midpoints, deltas = read_vs_file(args.comparison)
-    samples, scores, counts = score_samples(ctx, args.allps, midpoints, deltas)
-    groups = get_groups(args.manifest) if args.manifest else None
-    write_scores(args.output, scores, samples, counts, groups)
+    events = significant_events(args.comparison)
+    samples, scores, counts = score_table(ctx, args.allps, events)
+    write_report(args.output, samples, scores, counts, sample_groups(args.manifest) if args.manifest else None)

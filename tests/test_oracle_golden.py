@@ -203,7 +203,7 @@ def test_similarity_restatement_vs_reference_output(golden_dir):
     s, c = os.path.join(golden_dir, "similarity"), os.path.join(golden_dir, "compare")
     for vs, allps, want in ((os.path.join(c, "expected_out.tsv"), os.path.join(c, "in_allPS.tsv"), "expected_scores.tsv"),
                             (os.path.join(s, "in_vs.tsv"), os.path.join(s, "in_allPS.tsv"), "expected_scores_handmade.tsv")):
-        midpoints, deltas = sim.read_vs_file(vs)
+        events = sim.significant_events(vs)
         with open(allps) as fh:
             samples = fh.readline().rstrip().split("\t")[1:]
             names, rows = [], []
@@ -211,7 +211,7 @@ def test_similarity_restatement_vs_reference_output(golden_dir):
                 row = line.rstrip().split("\t")
                 names.append(row[0])
                 rows.append([float(x) for x in row[1:]])
-        mid, sign = sim.row_parameters(names, midpoints, deltas)
+        mid, sign = sim.row_parameters(names, events)
         scores, counts = O.similarity_scores(np.array(rows), mid, sign)
         lines = [f"{sm}\t{sc / ct:0.03f}\t{sc}\t{ct}\n"
                  for sc, sm, ct in sorted(zip(scores.tolist(), samples, counts.tolist()), reverse=True)]
