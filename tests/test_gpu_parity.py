@@ -559,3 +559,20 @@ def test_bh_fuzz(ctx):
         p = rng.random((n, cols)) ** 3
         p[rng.random((n, cols)) < 0.2] = 1.0
         np.testing.assert_allclose(ctx.bh_columns(p), O.bh_columns(p), rtol=1e-14, atol=0)
+
+
+def test_bh_high_word_runs(ctx):
+    """keys that agree in their high 32 bits: short runs of distinct values, long runs of one value, long
+    runs of distinct values (p-values that differ by a few ulps, as Fisher's "almost 1" results do)"""
+    rng = np.random.default_rng(808)
+    m = 5000
+    p = rng.random(m) ** 2
+    p[100:110] = 0.25 + np.arange(10)[::-1] * 1e-13
+    p[200:1200] = 1.0
+    p[1300:1330] = 0.125 + rng.permutation(30) * 1e-14
+    p[2000:2100] = 0.5 + rng.permutation(100) * 1e-12
+    p[3000:3400] = 1.0 - rng.integers(1, 4, size=400) * 2.0 ** -53
+    vec = p[rng.permutation(m)]
+    np.testing.assert_allclose(ctx.bh(vec), O.bh_fdr(vec), rtol=1e-14, atol=0)
+    cols = np.stack([p[rng.permutation(m)], p[rng.permutation(m)], rng.random(m)], axis=1)
+    np.testing.assert_allclose(ctx.bh_columns(cols), O.bh_columns(cols), rtol=1e-14, atol=0)
