@@ -215,6 +215,15 @@ int sdice_similarity(sdice_ctx* ctx, int64_t n, int32_t s, const double* ps, con
 int sdice_similarity_dev(sdice_ctx* ctx, int64_t n, int32_t s, const double* d_ps, const double* d_mid,
                          const int8_t* d_sign, int64_t* d_scores, int64_t* d_counts);
 
+/* ---- K9: per-row np.nanmean / np.nanstd over k selected columns (findOutliers.py:125-135), in the
+ * matrix's own dtype (0 float32, 1 float64), bit-identical to numpy: NaNs replaced by zero in place,
+ * numpy's pairwise summation, both divisions by the valid count in float64 then rounded.
+ * mean / std are arrays of that dtype, n_nan the number of NaNs among the selected columns. */
+int sdice_rowstats(sdice_ctx* ctx, int64_t n, int32_t s, const void* data, int dtype, const int32_t* idx, int32_t k,
+                   void* mean, void* std_, int32_t* n_nan);
+int sdice_rowstats_dev(sdice_ctx* ctx, int64_t n, int32_t s, const void* d_data, int dtype, const int32_t* d_idx,
+                       int32_t k, void* d_mean, void* d_std, int32_t* d_nan);
+
 /* ---- multi-GPU (new; the reference is single-process): one context per rank,
  *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque
  *      bytes created on rank 0 and distributed by the caller (any channel). */

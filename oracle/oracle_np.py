@@ -387,3 +387,32 @@ def similarity_scores(ps, mid, sign):
                     if float(ps[r, i]) > mid[r]:
                         scores[i] += 1
     return np.array(scores, dtype=np.int64), np.array(counts, dtype=np.int64)
+
+
+# --------------------------------------------------------------------------------------
+# findOutliers
+# --------------------------------------------------------------------------------------
+
+def find_outlier_lines(rows, cols, matrix, samples, null, cutoff):
+    """findOutliers.py:117-152 row by row -> list of output lines (without newline)."""
+    null_idx = np.argwhere(np.isin(cols, null))[:, 0]
+    out_idx = np.argwhere(np.isin(cols, samples))[:, 0]
+    lines = []
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for e, row in enumerate(matrix):
+                null_vals = row[null_idx]
+                if np.sum(np.isnan(null_vals)) / len(null_vals) > 0.2:
+                    continue
+                std = np.nanstd(null_vals)
+                if std < 0.001:
+                    continue
+                mean = np.nanmean(null_vals)
+                vals = row[out_idx]
+                z = (vals - mean) / std
+                for pos, x in enumerate(z):
+                    if x >= cutoff and abs(x - mean) >= cutoff:
+                        lines.append("\t".join(str(v) for v in (rows[e], cols[out_idx[pos]], x, vals[pos], mean, std)))
+    return lines

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sdice_sort_unique_u64": [ctxp, C.c_int64, vp, c_i64p],
     "sdice_similarity": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
     "sdice_similarity_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
+    "sdice_rowstats": [ctxp, C.c_int64, C.c_int32, vp, C.c_int, vp, C.c_int32, vp, vp, vp],
+    "sdice_rowstats_dev": [ctxp, C.c_int64, C.c_int32, vp, C.c_int, vp, C.c_int32, vp, vp, vp],
     "sdice_comm_unique_id": [ctxp, vp],
     "sdice_comm_init": [ctxp, vp, C.c_int, C.c_int],
     "sdice_comm_destroy": [ctxp],

@@ -226,6 +226,20 @@ class Context:
         check(self.lib.sdice_sort_unique_u64(self.h, keys.size, _ptr(keys), C.byref(n_unique)), "sdice_sort_unique_u64")
         return keys[: n_unique.value]
 
+    def rowstats(self, data, idx):
+        """per-row np.nanmean / np.nanstd over columns idx, bit-identical to numpy in data's dtype
+        (float32 / float64) -> (mean, std, n_nan); findOutliers.py:125-135"""
+        data = np.ascontiguousarray(data)
+        if data.dtype not in (np.float32, np.float64):
+            raise TypeError(f"rowstats: unsupported dtype {data.dtype}")
+        idx = _c(idx, np.int32)
+        n, s = data.shape
+        mean, std = np.zeros(n, data.dtype), np.zeros(n, data.dtype)
+        n_nan = np.zeros(n, np.int32)
+        check(self.lib.sdice_rowstats(self.h, n, s, _ptr(data), 0 if data.dtype == np.float32 else 1, _ptr(idx), idx.size,
+                                      _ptr(mean), _ptr(std), _ptr(n_nan)), "sdice_rowstats")
+        return mean, std, n_nan
+
     def similarity(self, ps, mid, sign):
         """similarity.py:25-47 -> (scores int64[s], counts int64[s]); ps float64 [n, s]"""
         ps, mid, sign = _c(ps, np.float64), _c(mid, np.float64), _c(sign, np.int8)

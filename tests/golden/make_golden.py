@@ -338,6 +338,41 @@ def main():
         fh.write("extra\t0.5\t0.5\t0.5\t0.5\t0.5\n")
     quiet(SIM.run_with, ns(comparison=os.path.join(sdir, "in_vs.tsv"), allps=os.path.join(sdir, "in_allPS.tsv"),
                            manifest=None, output=os.path.join(sdir, "expected_scores_handmade.tsv")))
+    # ------------------------------------------------------------------ findOutliers
+    import splicedice.findOutliers as FO
+    odir = fresh(os.path.join(HERE, "outliers"))
+    rng = np.random.default_rng(55)
+    n_ev, n_s = 400, 16
+    cols = np.array([f"samp{i}" for i in range(n_s)])
+    rows = np.array([f"chr2:{1000 + 13 * r}-{5000 + 17 * r}:-" for r in range(n_ev)])
+    base = rng.beta(0.7, 0.7, size=(n_ev, 1))
+    mat = np.clip(base + rng.normal(0, 0.03, size=(n_ev, n_s)), 0, 1)
+    mat = np.round(mat, 3)
+    spikes = rng.integers(0, n_ev, size=60)
+    mat[spikes, rng.integers(0, n_s, size=60)] = np.round(rng.random(60), 3)      # outlying samples
+    mat[rng.random((n_ev, n_s)) < 0.04] = np.nan
+    mat[7, :12] = np.nan                      # > 20 % NaN among the null group -> skipped
+    mat[8, :] = 0.5                           # std 0 -> skipped
+    mat[9, :] = np.nan
+    with open(os.path.join(odir, "samples.tsv"), "w") as fh:
+        for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+            fh.write(f"samp{i}\tpath{i}\n")
+        fh.write("not_in_table\tp\n")
+    with open(os.path.join(odir, "null.tsv"), "w") as fh:
+        for i in (15, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):          # order must not matter
+            fh.write(f"samp{i}\tpath{i}\n")
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        np.savez(os.path.join(odir, f"matrix_{tag}.npz"), cols=cols, rows=rows, data=mat.astype(dt))
+        for null, name in ((None, "self"), (os.path.join(odir, "null.tsv"), "null")):
+            _, text = quiet(FO.run_with, ns(psiSPLICEDICE=os.path.join(odir, f"matrix_{tag}.npz"),
+                                            manifest=os.path.join(odir, "samples.tsv"), nullMan=null, outlierCutoff=3,
+                                            dpsiThrsh=0.1))
+            with open(os.path.join(odir, f"expected_{tag}_{name}.txt"), "w") as fh:
+                fh.write(text)
+    _, text = quiet(FO.run_with, ns(psiSPLICEDICE=os.path.join(odir, "matrix_f32.npz"),
+                                    manifest=os.path.join(odir, "samples.tsv"), nullMan=None, outlierCutoff=2, dpsiThrsh=0.1))
+    with open(os.path.join(odir, "expected_f32_cutoff2.txt"), "w") as fh:
+        fh.write(text)
     print("golden fixtures written under", HERE)
 
 

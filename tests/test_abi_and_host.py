@@ -161,7 +161,9 @@ def test_dispatcher_names_and_flags():
     assert a.annotation == ""
     a = p.parse_args(["counts_to_ps", "-i", "c", "-o", "o", "-r"])
     assert a.recluster and a.clusters is None
-    for name in ("bam_to_junc_bed", "intron_coverage", "ir_table", "findOutliers", "subset", "select"):
+    a = p.parse_args(["findOutliers", "--psiSPLICEDICE", "m.npz", "-m", "man.tsv"])
+    assert a.nullMan is None and a.outlierCutoff == 3 and a.dpsiThrsh == 0.1
+    for name in ("bam_to_junc_bed", "intron_coverage", "ir_table", "subset", "select"):
         assert p.parse_args([name]).command == name
     a = p.parse_args(["similarity", "-c", "vs.tsv", "-a", "allps.tsv", "-o", "out.tsv"])
     assert a.manifest is None and a.comparison == "vs.tsv"

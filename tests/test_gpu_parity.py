@@ -576,3 +576,27 @@ def test_bh_high_word_runs(ctx):
     np.testing.assert_allclose(ctx.bh(vec), O.bh_fdr(vec), rtol=1e-14, atol=0)
     cols = np.stack([p[rng.permutation(m)], p[rng.permutation(m)], rng.random(m)], axis=1)
     np.testing.assert_allclose(ctx.bh_columns(cols), O.bh_columns(cols), rtol=1e-14, atol=0)
+
+
+# ------------------------------------------------------------------------------ row statistics (findOutliers)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rowstats_bit_identical_to_numpy(ctx, dtype):
+    """np.nanmean / np.nanstd per row over a column subset, in the matrix dtype, bit for bit"""
+    import warnings
+    rng = np.random.default_rng(1234)
+    for s, k in ((12, 10), (40, 12), (130, 100), (300, 129), (700, 500), (1100, 972), (1030, 1024), (9, 1)):
+        n = 200
+        data = np.round(rng.random((n, s)), 3).astype(dtype)
+        data[rng.random((n, s)) < 0.15] = np.nan
+        data[0, :] = np.nan
+        data[1, :] = 0.25
+        idx = np.sort(rng.permutation(s)[:k]).astype(np.int32)
+        mean, std, n_nan = ctx.rowstats(data, idx)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_mean = np.array([np.nanmean(r[idx]) for r in data], dtype=dtype)
+            want_std = np.array([np.nanstd(r[idx]) for r in data], dtype=dtype)
+        assert mean.dtype == dtype and std.dtype == dtype
+        assert np.array_equal(n_nan, np.isnan(data[:, idx]).sum(axis=1))
+        assert np.array_equal(mean, want_mean, equal_nan=True), (s, k)
+        assert np.array_equal(std, want_std, equal_nan=True), (s, k)

@@ -216,3 +216,16 @@ def test_similarity_restatement_vs_reference_output(golden_dir):
         lines = [f"{sm}\t{sc / ct:0.03f}\t{sc}\t{ct}\n"
                  for sc, sm, ct in sorted(zip(scores.tolist(), samples, counts.tolist()), reverse=True)]
         assert "".join(lines) == open(os.path.join(s, want)).read()
+
+
+def test_find_outliers_restatement_vs_reference_output(golden_dir):
+    from splicedice_amd import find_outliers as fo
+    d = os.path.join(golden_dir, "outliers")
+    samples = fo.first_fields(os.path.join(d, "samples.tsv"))
+    null = fo.first_fields(os.path.join(d, "null.tsv"))
+    for tag in ("f32", "f64"):
+        z = np.load(os.path.join(d, f"matrix_{tag}.npz"))
+        for name, grp, cut in (("self", samples, 3), ("null", null, 3)) + ((("cutoff2", samples, 2),) if tag == "f32" else ()):
+            lines = O.find_outlier_lines(z["rows"], z["cols"], z["data"], samples, grp, cut)
+            want = open(os.path.join(d, f"expected_{tag}_{name}.txt")).read()
+            assert "".join(line + "\n" for line in lines) == want, (tag, name)
