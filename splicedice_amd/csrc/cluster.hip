@@ -103,18 +103,6 @@ __global__ void __launch_bounds__(256) pack_keys_kernel(const int32_t* __restric
     idx[i] = (uint32_t)i;
 }
 
-__global__ void __launch_bounds__(256) decode_keys_kernel(const uint64_t* __restrict__ keys, int64_t n, Pack pk,
-                                                          uint64_t* __restrict__ ckL, uint64_t* __restrict__ ckR) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint64_t k = keys[p];
-    const uint64_t seg = k >> pk.seg_shift();
-    const uint64_t l = ((k >> pk.bN) & ((1ull << pk.bL) - 1ull)) + pk.min_left;
-    const uint64_t len = k & ((1ull << pk.bN) - 1ull);
-    ckL[p] = (seg << 32) | l;
-    ckR[p] = (seg << 32) | (l + len);
-}
-
 __device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ a, int64_t lo, int64_t hi, uint64_t t) {
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);
@@ -131,12 +119,37 @@ __global__ void __launch_bounds__(256) seg_table_kernel(const uint64_t* __restri
     seg_start[t] = lower_bound_u64(keys, 0, n, (uint64_t)t << pk.seg_shift());
 }
 
-// row of every sweep position (see header, step 3)
+// row of every sweep position (see header, step 3).  The same pass unpacks the composite sweep keys
+// (ckL = seg|left, ckR = seg|right), takes the 64-wide maxima of ckR and clears the small accumulators
+// of the neighbour kernels -- three launches and two memsets less on a latency-bound pipeline.
 __global__ void __launch_bounds__(256) rank_rows_kernel(const uint64_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ idx, int64_t n, Pack pk,
                                                         const int64_t* __restrict__ seg_start /* may be null */,
-                                                        uint32_t* __restrict__ srow, int32_t* __restrict__ row_of) {
+                                                        uint32_t* __restrict__ srow, int32_t* __restrict__ row_of,
+                                                        uint64_t* __restrict__ ckL, uint64_t* __restrict__ ckR,
+                                                        uint64_t* __restrict__ bmax,
+                                                        unsigned long long* __restrict__ reach_slots,
+                                                        int64_t* __restrict__ deg_tail) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < 1024) reach_slots[p] = 0ull;
+    if (p == 0) *deg_tail = 0;
+    {
+        uint64_t r = 0ull;
+        if (p < n) {
+            const uint64_t kk = keys[p];
+            const uint64_t sg = kk >> pk.seg_shift();
+            const uint64_t l = ((kk >> pk.bN) & ((1ull << pk.bL) - 1ull)) + pk.min_left;
+            r = (sg << 32) | (l + (kk & ((1ull << pk.bN) - 1ull)));
+            ckL[p] = (sg << 32) | l;
+            ckR[p] = r;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t y = __shfl_xor(r, o);
+            r = y > r ? y : r;
+        }
+        if ((threadIdx.x & 63) == 0 && p < n) bmax[p >> 6] = r;
+    }
     if (p >= n) return;
     const uint64_t k = keys[p];
     const int sh = pk.seg_shift();
@@ -329,7 +342,8 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     unsigned long long* red = (unsigned long long*)A.alloc(RED_SLOTS * RED_WORDS * 8);
     const int64_t nb64 = sd_ceil_div(n, 64);
     uint64_t* bmax = (uint64_t*)A.alloc((size_t)nb64 * 8);
-    if (!kA || !kB || !kC || !vA || !vB || !vC || !deg || !red || !bmax) return SDICE_ERR_NOMEM;
+    unsigned long long* reach_slots = (unsigned long long*)A.alloc(1024 * 8);
+    if (!kA || !kB || !kC || !vA || !vB || !vC || !deg || !red || !bmax || !reach_slots) return SDICE_ERR_NOMEM;
 
     // ---- field ranges (and validation) in one pass, one read-back
     // every block ends with 8 atomics; RED_SLOTS copies of the accumulators (one 128-B line each,
@@ -383,7 +397,6 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
         const uint64_t mask = total_bits >= 64 ? ~0ull : ((1ull << total_bits) - 1ull);
         SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vA, kB, vB, kC, vC, mask));   // -> kB (keys), vB (input index)
         ckL = kA; ckR = kC;
-        SD_LAUNCH(ctx, "decode_keys_kernel", decode_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, kB, n, pk, ckL, ckR);
         const int64_t n_seg = (int64_t)(((max_chrom << 1) | 1ull) + 1ull);   // seg values are < n_seg
         int64_t* seg_start = nullptr;
         if (n_seg <= (1 << 20)) {
@@ -393,8 +406,8 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
                       n_seg + 1, seg_start);
         }
         srow = vA;
-        SD_LAUNCH(ctx, "rank_rows_kernel", rank_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, kB, vB, n, pk,
-                  (const int64_t*)seg_start, srow, d_row_of);
+        SD_LAUNCH(ctx, "rank_rows_kernel", rank_rows_kernel, dim3(grid_for(n > 1024 ? n : 1024, 256)), dim3(256), 0, kB, vB,
+                  n, pk, (const int64_t*)seg_start, srow, d_row_of, ckL, ckR, bmax, reach_slots, deg + n);
         pmax = kB;   // the sorted keys are dead after rank_rows (stream order)
     } else {
         int32_t* rowL = (int32_t*)A.alloc(N * 4);
@@ -425,13 +438,13 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
         pmax = kB;  // seg dead after sweep_keys
     }
     SD_TRY(sd_inclusive_max_scan_u64(ctx, n, ckR, pmax));
-    SD_LAUNCH(ctx, "blockmax_kernel", blockmax_kernel, dim3((unsigned)nb64), dim3(64), 0, ckR, n, bmax);
 
     // ---- degrees -> row_ptr
-    unsigned long long* reach_slots = (unsigned long long*)A.alloc(1024 * 8);
-    if (!reach_slots) return SDICE_ERR_NOMEM;
-    SD_HIP(hipMemsetAsync(reach_slots, 0, 1024 * 8, ctx->stream));
-    SD_HIP(hipMemsetAsync(deg + n, 0, 8, ctx->stream));
+    if (!packed) {      // (the packed path did these three inside rank_rows_kernel)
+        SD_LAUNCH(ctx, "blockmax_kernel", blockmax_kernel, dim3((unsigned)nb64), dim3(64), 0, ckR, n, bmax);
+        SD_HIP(hipMemsetAsync(reach_slots, 0, 1024 * 8, ctx->stream));
+        SD_HIP(hipMemsetAsync(deg + n, 0, 8, ctx->stream));
+    }
     SD_LAUNCH(ctx, "neighbours_count_kernel", (neighbours_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, ckL, ckR,
               pmax, bmax, srow, n, deg, (const int64_t*)nullptr, (int32_t*)nullptr, reach_slots);
     SD_TRY(sd_exclusive_scan_i64(ctx, n + 1, deg, d_row_ptr, nullptr));

@@ -1,5 +1,6 @@
-// Device scans (3 launches each: per-block reduce, single-block scan of the block sums,
-// per-block apply).  Used for row_ptr (sum), the segmented prefix maximum of the clustering
+// Device scans: per-block reduce, then per-block apply in which every block folds the aggregates of
+// its predecessors itself (2 launches; beyond 4096 blocks a single-block scan of the aggregates sits
+// in between, 3 launches).  Used for row_ptr (sum), the segmented prefix maximum of the clustering
 // (max on composite keys) and the BH running minimum (min on IEEE bit patterns).
 #include "common.h"
 
@@ -139,6 +140,57 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const typename
     }
 }
 
+// Two-launch variant for up to SCAN_SELF_MAX blocks: every block folds the aggregates of the blocks
+// before it by itself (a few KB from L2) instead of waiting for a single-block scan of the
+// aggregates -- one launch less on pipelines whose kernels sit at the ~5 us launch/drain floor.
+// All three operators are associative and commutative, so the fold order is free.
+constexpr int64_t SCAN_SELF_MAX = 4096;
+
+template <typename Op, bool EXCLUSIVE>
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_self_kernel(const typename Op::T* __restrict__ in, int64_t n,
+                                                                       const typename Op::T* __restrict__ block_sums,
+                                                                       typename Op::T* __restrict__ out,
+                                                                       typename Op::T* __restrict__ total_out) {
+    typedef typename Op::T T;
+    __shared__ T wsum[SCAN_THREADS / 64];
+    __shared__ T last_incl[SCAN_THREADS];
+    __shared__ T fold[SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T acc = Op::identity();
+    for (int64_t i = tid; i < (int64_t)blockIdx.x; i += SCAN_THREADS) acc = Op::apply(acc, block_sums[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = (unsigned)((uint64_t)acc & 0xffffffffu), hi = (unsigned)((uint64_t)acc >> 32);
+        lo = __shfl_xor(lo, o);
+        hi = __shfl_xor(hi, o);
+        acc = Op::apply(acc, (T)(((uint64_t)hi << 32) | lo));
+    }
+    if (lane == 0) fold[w] = acc;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_THREADS * SCAN_ITEMS + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) v[q] = (base + q < n) ? in[base + q] : Op::identity();
+    T tot;
+    block_scan_items<Op>(v, tot, wsum);          // (contains the barriers that publish fold[])
+    T bp = Op::identity();
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) bp = Op::apply(bp, fold[k]);
+    if (total_out && blockIdx.x == gridDim.x - 1 && tid == 0) *total_out = Op::apply(bp, tot);
+    if (EXCLUSIVE) {
+        last_incl[threadIdx.x] = v[SCAN_ITEMS - 1];
+        __syncthreads();
+        const T tprev = threadIdx.x == 0 ? Op::identity() : last_incl[threadIdx.x - 1];
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS; ++q) {
+            const T e = q == 0 ? tprev : v[q - 1];
+            if (base + q < n) out[base + q] = Op::apply(bp, e);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS; ++q)
+            if (base + q < n) out[base + q] = Op::apply(bp, v[q]);
+    }
+}
+
 template <typename Op, bool EXCLUSIVE>
 int scan_impl(sdice_ctx* ctx, int64_t n, const typename Op::T* d_in, typename Op::T* d_out,
               typename Op::T* d_total, const char* tag) {
@@ -153,6 +205,11 @@ int scan_impl(sdice_ctx* ctx, int64_t n, const typename Op::T* d_in, typename Op
     if (!sums) return SDICE_ERR_NOMEM;
     (void)tag;
     SD_LAUNCH(ctx, "scan_reduce_kernel", (scan_reduce_kernel<Op>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d_in, n, sums);
+    if (nb <= SCAN_SELF_MAX) {
+        SD_LAUNCH(ctx, "scan_apply_self_kernel", (scan_apply_self_kernel<Op, EXCLUSIVE>), dim3((unsigned)nb),
+                  dim3(SCAN_THREADS), 0, d_in, n, sums, d_out, d_total);
+        return SDICE_OK;
+    }
     SD_LAUNCH(ctx, "scan_sums_kernel", (scan_sums_kernel<Op>), dim3(1), dim3(SCAN_THREADS), 0, sums, nb, d_total);
     SD_LAUNCH(ctx, "scan_apply_kernel", (scan_apply_kernel<Op, EXCLUSIVE>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0,
               d_in, n, sums, d_out);
