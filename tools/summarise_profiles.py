@@ -15,10 +15,12 @@ for wl in ("quant", "compare", "pairwise", "e2e"):
     if not files:
         continue
     rows = list(csv.DictReader(open(files[0])))
-    with open(os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"), "w") as fh:
-        fh.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
+    with open(os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as fh:
+        out = csv.writer(fh)                   # kernel names carry template commas: quoted
+        out.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
         for r in rows:
-            fh.write(f'{short(r["Name"])},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.0f},{r["Percentage"]},{r["MinNs"]},{r["MaxNs"]}\n')
+            out.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], f'{float(r["AverageNs"]):.0f}', r["Percentage"],
+                          r["MinNs"], r["MaxNs"]])
     bj = os.path.join(src, f"{wl}_bench.json")
     if os.path.exists(bj):
         with open(bj) as fh, open(os.path.join(dst, f"{tag}_{wl}_bench_under_rocprof.json"), "w") as out:
@@ -44,11 +46,12 @@ for wl, (dom, n, s) in DOMINANT.items():
             traffic.setdefault(short(k), {})[cname] = sum(v) / len(v)
     if not traffic:
         continue
-    with open(os.path.join(dst, f"{tag}_{wl}_pmc.csv"), "w") as fh:
-        fh.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch_corrected\n")
+    with open(os.path.join(dst, f"{tag}_{wl}_pmc.csv"), "w", newline="") as fh:
+        out = csv.writer(fh)
+        out.writerow(["kernel", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_per_launch_corrected"])
         for k, v in sorted(traffic.items()):
             f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
-            fh.write(f"{k},{f:.1f},{w:.1f},{(2 * f + w) * 1024:.0f}\n")
+            out.writerow([k, f"{f:.1f}", f"{w:.1f}", f"{(2 * f + w) * 1024:.0f}"])
     hit = [v for k, v in traffic.items() if k.startswith(dom)]
     if hit:
         records.append({"workload": wl, "n": n, "s": s, "kernel": dom,
