@@ -57,20 +57,17 @@ def exclusion_csr(events, clusters):
 
 
 def add_parser(parser):
+    # same flags, defaults and choices as pairwise_fisher.py:71-111
     parser.add_argument("--inclusionSPLICEDICE", type=str, required=True,
-                        help="Compressed NPZ formatted Inclusion count matrix from quantSPLICEDICE.")
-    parser.add_argument("-c", "--clusters", type=str, required=True, help="Clusters table.")
+                        help="inclusion count table written by `splicedice quant` (*_inclusionCounts.tsv)")
+    parser.add_argument("-c", "--clusters", type=str, required=True,
+                        help="cluster table written by `splicedice quant` (*_allClusters.tsv)")
     parser.add_argument("--chi2", action="store_true", default=False,
-                        help="Use X^2 instead of fishers. Quicker, not as sensitive.")
+                        help="Yates-corrected chi-square per pair instead of Fisher's exact test")
     parser.add_argument("--multiple_test_correction", default="pairwise", choices=["pairwise", "all", "none"],
-                        help="Correction via Benjamini-Hochberg. Options are "
-                             "[pairwise (default): all p-values per sample pair; "
-                             "all: all p-values for every sample pair together;\n"
-                             "none: no multiple test correction]")
-    parser.add_argument("-f", "--filter_list",
-                        help="txt file where each line is a event to analyze, can speed up fisher test analysis")
-    parser.add_argument("-o", "--output", default="pairwise.tsv",
-                        help="tab-separated output filename (default uses input prefix)")
+                        help="Benjamini-Hochberg scope: per sample pair (default), over all p-values, or off")
+    parser.add_argument("-f", "--filter_list", help="text file with one event per line: only these rows are analysed")
+    parser.add_argument("-o", "--output", default="pairwise.tsv", help="output table (tab separated)")
 
 
 def run_with(args, ctx=None):
