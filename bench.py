@@ -197,7 +197,7 @@ class CompareWorkload:
         self.d_q = ctx.empty(n, np.float64)
         self.units = n
         if max(self.g1.size, self.g2.size) > 64:
-            self.kernel = "ranksum_wave_kernel" if max(self.g1.size, self.g2.size) <= 1024 else "ranksum_block_kernel"
+            self.kernel = "ranksum_count_kernel" if max(self.g1.size, self.g2.size) <= 1024 else "ranksum_block_kernel"
         self.alg_bytes = (4.0 * s + 28.0) * n          # 4*S_sel + 28 B per junction
 
     def step(self):
@@ -305,7 +305,7 @@ class E2EWorkload(QuantWorkload):
     The PS shard never leaves HBM; only the per-junction p-values are exchanged.
     """
     name = "quant + compare_sample_sets end to end"
-    kernel = "ranksum_wave_kernel"
+    kernel = "ranksum_count_kernel"
     needs_comm = True
 
     def __init__(self, ctx, rank, n, s):
@@ -323,7 +323,7 @@ class E2EWorkload(QuantWorkload):
         self.d_q = ctx.empty(n, np.float64)
         self.collective = "none (1 GPU)"
         big = max(self.g1.size, self.g2.size)
-        self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_wave_kernel" if big <= 1024 else "ranksum_block_kernel"
+        self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
         self.alg_bytes = (4.0 * s + 28.0) * n           # rank-sum: 4*S_sel + 28 B per junction
 
     def setup_comm(self, dist, world):

@@ -213,7 +213,7 @@ static hipEvent_t pool_get(sdice_ctx* ctx) {
 
 int sd_prof_begin(sdice_ctx* ctx, const char* name) {
     if (!ctx->prof_on) return -1;
-    if (ctx->prof_mode == 2 && strcmp(name, "ps_tile_kernel") != 0 && strcmp(name, "ranksum_wave_kernel") != 0 && strcmp(name, "ranksum_pair_kernel") != 0 && strcmp(name, "ranksum_lane_kernel") != 0 &&
+    if (ctx->prof_mode == 2 && strcmp(name, "ps_tile_kernel") != 0 && strcmp(name, "ranksum_wave_kernel") != 0 && strcmp(name, "ranksum_count_kernel") != 0 && strcmp(name, "ranksum_pair_kernel") != 0 && strcmp(name, "ranksum_lane_kernel") != 0 &&
         strcmp(name, "ranksum_block_kernel") != 0 && strcmp(name, "fisher_pairs_kernel") != 0 &&
         strcmp(name, "rccl_allgather") != 0)
         return -1;

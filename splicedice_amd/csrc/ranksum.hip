@@ -16,6 +16,9 @@
 // Kernels (auto dispatch: lane pair for groups <= 64, wave for <= 1024, block above):
 //   ranksum_pair_kernel  (n1, n2 <= 64): the lane kernel's machinery with TWO lanes per row (one
 //       per group), half the LDS per wave, twice the resident waves (see its comment).
+//   ranksum_count_kernel (n1, n2 in 65..1024, rows of 3-decimal PS values -- what compare_sample_sets
+//       always sees): one WAVE per row, the two groups become histograms over the 1001 possible
+//       values, nothing is sorted (see its comment); other rows are left to
 //   ranksum_wave_kernel  (n1, n2 <= 1024): one WAVE per row, 64*E-element bitonic network held
 //       in VGPRs across the wave, no workgroup barriers (see the kernel's comment).
 //   ranksum_lane_kernel  (n1, n2 <= 64): one LANE per row.  A wave stages 64 rows (only the
@@ -602,11 +605,13 @@ __device__ __forceinline__ float wave_pairwise_sum(const float* C, int nv, int l
     return out;
 }
 
+constexpr unsigned char RS_REDO = 0xFF;     // `tested` mark: row left to the sorting kernel by ranksum_count_kernel
+
 template <int E>
 __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restrict__ ps, int64_t n, int s,
                                                            const int32_t* __restrict__ g1, int n1,
                                                            const int32_t* __restrict__ g2, int n2, int ch,
-                                                           RsOut o) {
+                                                           int redo_only, RsOut o) {
     extern __shared__ __align__(16) float smemw[];
     constexpr int N = 64 * E;
     constexpr int WSTRIDE = 2 * N + 40;
@@ -635,7 +640,15 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
       const int rows_here = (int)min((int64_t)ch, n - row0);
       int s_nv1 = 0, s_nv2 = 0, s_u2 = 0;
       float s_med1 = 0.f, s_med2 = 0.f, s_sum1 = 0.f, s_sum2 = 0.f;
+      // redo mode (after ranksum_count_kernel): only the rows it marked RS_REDO are computed and written
+      unsigned long long todo = ~0ull;
+      if (redo_only) {
+          const bool marked = lane < rows_here && o.tested[row0 + lane] == RS_REDO;
+          todo = __ballot(marked);
+          if (todo == 0ull) continue;
+      }
       for (int ri = 0; ri < rows_here; ++ri) {
+        if (!((todo >> ri) & 1ull)) continue;
         const float* prow = ps + (row0 + ri) * s;
         float x[E], y[E];
 #pragma unroll
@@ -709,7 +722,7 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
             s_med1 = med1; s_med2 = med2; s_sum1 = sum1; s_sum2 = sum2;
         }
       }
-      if (lane < rows_here) {
+      if (lane < rows_here && ((todo >> lane) & 1ull)) {
         const int64_t row = row0 + lane;
         const bool tested = s_nv1 >= 3 && s_nv2 >= 3;
         float mean1 = 0.f, mean2 = 0.f;
@@ -723,6 +736,215 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
             tested ? ((unsigned long long)(unsigned)s_u2 | ((unsigned long long)s_nv1 << 32) | ((unsigned long long)s_nv2 << 48))
                    : 0ull;
         o.tested[row] = tested ? 1 : 0;
+        reinterpret_cast<unsigned long long*>(o.p)[row] = packed;
+        o.med1[row] = s_med1; o.med2[row] = s_med2;
+        o.mean1[row] = mean1; o.mean2[row] = mean2;
+        o.delta[row] = s_med1 - s_med2;
+      }
+    }
+}
+
+// ------------------------------------------------------------------ counting variant (quantised PS)
+// compare_sample_sets always sees PS values that went through the '.3f' text of _allPS.tsv
+// (SPLICEDICE.py:353 -> compareSampleSets.py:202), i.e. float32(k / 1000.0) for k = 0..1000: a row's
+// two groups are then two HISTOGRAMS over 1001 bins and nothing has to be sorted:
+//   2U = sum_v a_v * (2 * #{b < v} + b_v),   medians = the bins where the cumulative counts cross n/2.
+// One wave per row as in the wave kernel (same ordered compaction and numpy pairwise sums for the
+// means); the histogram of both groups is one array of packed 16+16-bit counters in LDS, filled with
+// LDS atomics (the two heavy bins 0.000 and 1.000 are counted with ballots instead), scanned with
+// 16 bins per lane.  A row holding any value that is NOT exactly float32(k/1000) is left to the
+// sorting kernel: it is marked RS_REDO in `tested` and ranksum_wave_kernel is run over the marked rows.
+constexpr int RS_BINS = 1024;            // 1001 used
+#ifndef RS_BALLOT_EXTREMES
+#define RS_BALLOT_EXTREMES 1
+#endif
+
+// (occupancy hint: the kernel is latency bound; capping it at 128 VGPRs -- 4 waves per SIMD -- costs
+//  E = 8 two spilled dwords and buys 25 %; E = 16 would spill 55 dwords and keeps its 2 waves)
+template <int E>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4 ? 6 : E <= 8 ? 5 : 3, 8))) ranksum_count_kernel(const float* __restrict__ ps, int64_t n, int s,
+                                                            const int32_t* __restrict__ g1, int n1,
+                                                            const int32_t* __restrict__ g2, int n2, int ch,
+                                                            RsOut o) {
+    extern __shared__ __align__(16) float smemc[];
+    constexpr int N = 64 * E;
+    constexpr int WSTRIDE = 2 * N + 40 + RS_BINS + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    float* T = smemc;                                          // T[k] = float32(k / 1000.0), shared by the block
+    float* SA = smemc + 1008 + (size_t)wave * WSTRIDE;
+    float* SB = SA + N;
+    float* leaf_sum = SB + N;
+    int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);
+    unsigned* H = reinterpret_cast<unsigned*>(SB + N + 40);    // [RS_BINS] a_v | b_v << 16
+    for (int k = threadIdx.x; k < 1008; k += blockDim.x) T[k] = (float)((double)k / 1000.0);
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int idx1[E], idx2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = e * 64 + lane;
+        idx1[e] = k < n1 ? g1[k] : -1;
+        idx2[e] = k < n2 ? g2[k] : -1;
+    }
+    const int64_t n_chunks = (n + ch - 1) / ch;
+    for (int64_t c = (int64_t)blockIdx.x * wpb + wave; c < n_chunks; c += (int64_t)gridDim.x * wpb) {
+      const int64_t row0 = c * ch;
+      const int rows_here = (int)min((int64_t)ch, n - row0);
+      int s_nv1 = 0, s_nv2 = 0, s_u2 = 0, s_redo = 0;
+      float s_med1 = 0.f, s_med2 = 0.f, s_sum1 = 0.f, s_sum2 = 0.f;
+      for (int ri = 0; ri < rows_here; ++ri) {
+        const float* prow = ps + (row0 + ri) * s;
+        float x[E], y[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            x[e] = idx1[e] >= 0 ? prow[idx1[e]] : __builtin_nanf("");
+            y[e] = idx2[e] >= 0 ? prow[idx2[e]] : __builtin_nanf("");
+        }
+        // bin of every value and the check that the value IS its bin's float; kk[e] packs (bin + 1) of the
+        // group-1 value in the low half and of the group-2 value in the high half, 0 = NaN
+        unsigned kk[E];
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            unsigned packed_k = 0;
+            {
+                const float v = x[e];
+                const float kf = rintf(v * 1000.0f);
+                const bool inr = kf >= 0.0f && kf <= 1000.0f;        // false for NaN
+                const int k = inr ? (int)kf : 0;
+                ok = ok && (v != v || (inr && T[k] == v));
+                packed_k = (v != v) ? 0u : (unsigned)(k + 1);
+            }
+            {
+                const float v = y[e];
+                const float kf = rintf(v * 1000.0f);
+                const bool inr = kf >= 0.0f && kf <= 1000.0f;
+                const int k = inr ? (int)kf : 0;
+                ok = ok && (v != v || (inr && T[k] == v));
+                packed_k |= (v != v) ? 0u : ((unsigned)(k + 1) << 16);
+            }
+            kk[e] = packed_k;
+        }
+        if (__ballot(ok) != ~0ull) {                 // some value is not a 3-decimal float: the sorting kernel's row
+            if (lane == ri) s_redo = 1;
+            continue;
+        }
+        SD_WAVE_SYNC();          // the previous row's readers are done with the wave's LDS
+        int nv1 = 0, nv2 = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool v1 = (kk[e] & 0xffffu) != 0u;
+            const unsigned long long m1 = __ballot(v1);
+            if (v1) SA[nv1 + __popcll(m1 & lt_mask)] = x[e];
+            nv1 += __popcll(m1);
+            const bool v2 = (kk[e] >> 16) != 0u;
+            const unsigned long long m2 = __ballot(v2);
+            if (v2) SB[nv2 + __popcll(m2 & lt_mask)] = y[e];
+            nv2 += __popcll(m2);
+        }
+        // clear the histogram: 16 words per lane
+#pragma unroll
+        for (int q = 0; q < RS_BINS / 64 / 4; ++q) reinterpret_cast<uint4*>(H)[lane * (RS_BINS / 64 / 4) + q] = make_uint4(0, 0, 0, 0);
+        SD_WAVE_SYNC();
+        if (nv1 < 3 || nv2 < 3) {          // wave-uniform
+            if (lane == ri) { s_nv1 = nv1; s_nv2 = nv2; }
+            continue;
+        }
+        const float sum1 = wave_pairwise_sum(SA, nv1, lane, leaf_off, leaf_sum);
+        const float sum2 = wave_pairwise_sum(SB, nv2, lane, leaf_off, leaf_sum);
+        // histogram: ballots for the two heavy bins, LDS atomics for the rest
+        unsigned c_lo = 0, c_hi = 0;         // packed (group 1 | group 2 << 16) counts of bins 0 and 1000
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int kxe = (int)(kk[e] & 0xffffu) - 1, kye = (int)(kk[e] >> 16) - 1;     // -1 = NaN
+            if (RS_BALLOT_EXTREMES) {
+                c_lo += (unsigned)__popcll(__ballot(kxe == 0)) + ((unsigned)__popcll(__ballot(kye == 0)) << 16);
+                c_hi += (unsigned)__popcll(__ballot(kxe == 1000)) + ((unsigned)__popcll(__ballot(kye == 1000)) << 16);
+                if (kxe > 0 && kxe < 1000) atomicAdd(&H[kxe], 1u);
+                if (kye > 0 && kye < 1000) atomicAdd(&H[kye], 0x10000u);
+            } else {
+                if (kxe >= 0) atomicAdd(&H[kxe], 1u);
+                if (kye >= 0) atomicAdd(&H[kye], 0x10000u);
+            }
+        }
+        if (RS_BALLOT_EXTREMES) {            // the two ballot-counted bins join the histogram (no atomics touched them)
+            if (lane == 0) H[0] = c_lo;
+            if (lane == 1) H[1000] = c_hi;
+        }
+        SD_WAVE_SYNC();
+        // scan: lane owns bins [16 * lane, 16 * lane + 16)
+        int local = 0, cumA0, cumB0, totA, totB;
+        {
+            unsigned w[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 t4 = reinterpret_cast<const uint4*>(H)[lane * 4 + q];
+                w[4 * q] = t4.x; w[4 * q + 1] = t4.y; w[4 * q + 2] = t4.z; w[4 * q + 3] = t4.w;
+            }
+            unsigned tot = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += w[q];           // halves stay below 2^16 (at most 1024 values per group)
+            unsigned pre = tot;
+#pragma unroll
+            for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                const unsigned up = __shfl_up(pre, ofs);
+                if (lane >= ofs) pre += up;
+            }
+            pre -= tot;
+            cumA0 = (int)(pre & 0xffffu); cumB0 = (int)(pre >> 16);
+            totA = (int)(tot & 0xffffu); totB = (int)(tot >> 16);
+            int cumB = cumB0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int a = (int)(w[q] & 0xffffu), b = (int)(w[q] >> 16);
+                local += a * (2 * cumB + b);
+                cumB += b;
+            }
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) local += __shfl_xor(local, ofs);
+        // medians: the bin where a group's cumulative count crosses a middle position.  The lane whose 16
+        // bins contain the position is found with a ballot; its 16 counters are then examined by lanes
+        // 0..15 together (prefix by shuffles, crossing by a second ballot) -- uniform, no divergent walk.
+        auto find_bin = [&](int target, bool second) -> int {
+            const int c0 = second ? cumB0 : cumA0, tt = second ? totB : totA;
+            const int L = __ffsll((long long)__ballot(target >= c0 && target < c0 + tt)) - 1;
+            const int base = __shfl(c0, L);
+            const unsigned wq = lane < 16 ? H[L * 16 + lane] : 0u;
+            int inc = second ? (int)(wq >> 16) : (int)(wq & 0xffffu);
+#pragma unroll
+            for (int ofs = 1; ofs < 16; ofs <<= 1) {
+                const int up = __shfl_up(inc, ofs);
+                if (lane >= ofs) inc += up;
+            }
+            return L * 16 + (__ffsll((long long)__ballot(lane < 16 && target < base + inc)) - 1);
+        };
+        const int hA = nv1 >> 1, hB = nv2 >> 1;
+        const int binA1 = find_bin(hA, false), binB1 = find_bin(hB, true);
+        const int binA0 = (nv1 & 1) ? binA1 : find_bin(hA - 1, false);      // wave-uniform branches
+        const int binB0 = (nv2 & 1) ? binB1 : find_bin(hB - 1, true);
+        // np.median: odd -> middle value; even -> (v[h-1] + v[h]) / 2 in float32
+        const float a0 = T[binA0], a1 = T[binA1], b0 = T[binB0], b1 = T[binB1];
+        const float med1 = (nv1 & 1) ? a1 : (a0 + a1) / 2.0f;
+        const float med2 = (nv2 & 1) ? b1 : (b0 + b1) / 2.0f;
+        if (lane == ri) {
+            s_nv1 = nv1; s_nv2 = nv2; s_u2 = local;
+            s_med1 = med1; s_med2 = med2; s_sum1 = sum1; s_sum2 = sum2;
+        }
+      }
+      if (lane < rows_here) {
+        const int64_t row = row0 + lane;
+        const bool tested = s_nv1 >= 3 && s_nv2 >= 3;
+        float mean1 = 0.f, mean2 = 0.f;
+        if (tested) {
+            mean1 = s_sum1 / (float)s_nv1;
+            mean2 = s_sum2 / (float)s_nv2;
+        }
+        const unsigned long long packed =
+            tested ? ((unsigned long long)(unsigned)s_u2 | ((unsigned long long)s_nv1 << 32) | ((unsigned long long)s_nv2 << 48))
+                   : 0ull;
+        o.tested[row] = s_redo ? RS_REDO : (tested ? 1 : 0);
         reinterpret_cast<unsigned long long*>(o.p)[row] = packed;
         o.med1[row] = s_med1; o.med2[row] = s_med2;
         o.mean1[row] = mean1; o.mean2[row] = mean2;
@@ -746,7 +968,7 @@ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 template <int E>
 int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* g1, int n1, const int32_t* g2,
-                int n2, RsOut o) {
+                int n2, RsOut o, bool counting) {
     const int waves = 4;
     const size_t lds = (size_t)waves * (2 * 64 * E + 40) * 4;
     // rows per chunk: as many as keeps every wave slot of the chip (32 per CU) busy twice over
@@ -756,8 +978,16 @@ int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     int64_t blocks = sd_ceil_div(sd_ceil_div(n, ch), waves);
     const int64_t cap = (int64_t)ctx->n_cu * 8;
     if (blocks > cap) blocks = cap;
+    if (counting) {
+        // histogram path for rows of 3-decimal PS values; the sorting kernel then takes the rows it marked
+        const size_t lds_c = (size_t)(1008 + waves * (2 * 64 * E + 40 + RS_BINS + 8)) * 4;
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_count_kernel<E>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        SD_LAUNCH(ctx, "ranksum_count_kernel", (ranksum_count_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds_c,
+                  d_ps, n, s, g1, n1, g2, n2, ch, o);
+    }
     SD_LAUNCH(ctx, "ranksum_wave_kernel", (ranksum_wave_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
-              s, g1, n1, g2, n2, ch, o);
+              s, g1, n1, g2, n2, ch, counting ? 1 : 0, o);
     SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
               o.p, o.z);
     return SDICE_OK;
@@ -822,7 +1052,7 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         return SDICE_OK;
     }
     SD_ARG(d_ps, "ps is NULL");
-    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block, 3 wave, 4 lane pair
+    const int64_t variant = ctx->param("ranksum.variant", 0);  // 0 auto, 1 lane, 2 block, 3 wave (sorting only), 4 lane pair, 5 counting + wave
     const bool lane_ok = n1 <= 64 && n2 <= 64;
     SD_ARG((variant != 1 && variant != 4) || lane_ok, "lane variants need n1, n2 <= 64");
     if ((variant == 0 && lane_ok) || variant == 1 || variant == 4) {
@@ -847,14 +1077,16 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         }
     }
     const int big = n1 > n2 ? n1 : n2;
-    SD_ARG(variant != 3 || big <= 1024, "wave variant needs n1, n2 <= 1024");
-    if ((variant == 0 && big <= 1024) || variant == 3) {
+    SD_ARG((variant != 3 && variant != 5) || big <= 1024, "wave / counting variants need n1, n2 <= 1024");
+    if ((variant == 0 && big <= 1024) || variant == 3 || variant == 5) {
+        // auto and 5: histogram kernel for rows of 3-decimal values + sorting kernel for the rest; 3: sorting only
+        const bool counting = variant != 3;
         switch (next_pow2(big < 64 ? 64 : big) / 64) {
-            case 1: return launch_wave<1>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
-            case 2: return launch_wave<2>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
-            case 4: return launch_wave<4>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
-            case 8: return launch_wave<8>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
-            default: return launch_wave<16>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            case 1: return launch_wave<1>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o, counting);
+            case 2: return launch_wave<2>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o, counting);
+            case 4: return launch_wave<4>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o, counting);
+            case 8: return launch_wave<8>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o, counting);
+            default: return launch_wave<16>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o, counting);
         }
     }
     const int P1 = next_pow2(n1), P2 = next_pow2(n2);

@@ -600,3 +600,30 @@ def test_rowstats_bit_identical_to_numpy(ctx, dtype):
         assert np.array_equal(n_nan, np.isnan(data[:, idx]).sum(axis=1))
         assert np.array_equal(mean, want_mean, equal_nan=True), (s, k)
         assert np.array_equal(std, want_std, equal_nan=True), (s, k)
+
+
+def test_ranksum_counting_and_sorting_rows_mixed(ctx):
+    """groups of 65..1024: rows of 3-decimal values take the histogram kernel, any other row the sorting
+    kernel, within one call; both must agree with the oracle (and with the sorting kernel alone)"""
+    rng = np.random.default_rng(77)
+    for n1, n2 in ((70, 90), (500, 500), (1024, 130)):
+        s, n = n1 + n2, 150
+        ps = synth.make_ps_matrix(n, s, seed=n1 + n2, nan_frac=0.07)          # 3-decimal values
+        odd = rng.choice(n, size=40, replace=False)
+        ps[odd[:20], 5] = np.float32(0.1234567)                              # one non-quantised value in the row
+        ps[odd[20:]] = rng.random((20, s)).astype(np.float32)                # fully continuous rows
+        ps[odd[25], :] = np.nan
+        ps[3, : s - 2] = np.nan                                              # untested
+        ps[4, :] = 0.0
+        ps[5, :] = 1.0
+        ps[6, :n1] = 0.0
+        ps[6, n1:] = 1.0                                                     # complete separation
+        g1, g2 = np.arange(n1, dtype=np.int32), np.arange(n1, s, dtype=np.int32)
+        want = O.compare_rows(ps, g1, g2)
+        for variant in (0, 3, 5):
+            ctx.set_param("ranksum.variant", variant)
+            try:
+                got = ctx.ranksum(ps, g1, g2)
+            finally:
+                ctx.set_param("ranksum.variant", 0)
+            _check_ranksum(got, want)
