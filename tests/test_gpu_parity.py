@@ -470,7 +470,7 @@ def test_ranksum_fuzz_shapes(ctx):
         g1, g2 = np.sort(cols[:n1]), np.sort(cols[n1:n1 + n2])
         want = O.compare_rows(ps, g1, g2)
         big = max(n1, n2)
-        variants = [0, 2] + ([1, 4] if big <= 64 else []) + ([3] if big <= 1024 else [])
+        variants = [0, 2] + ([1, 4] if big <= 64 else []) + ([3, 5] if big <= 1024 else [])
         for variant in variants:
             ctx.set_param("ranksum.variant", variant)
             try:
