@@ -627,3 +627,27 @@ def test_ranksum_counting_and_sorting_rows_mixed(ctx):
             finally:
                 ctx.set_param("ranksum.variant", 0)
             _check_ranksum(got, want)
+
+
+def test_chi2_fuzz_magnitudes(ctx):
+    """Yates chi-square p-values over several count magnitudes (tiny tables where the correction clips
+    the statistic to zero, large tables where p underflows towards 0)"""
+    rng = np.random.default_rng(404)
+    for mean_i, mean_e in ((1.5, 3), (8, 20), (200, 900), (20000, 50000)):
+        incl = (rng.poisson(mean_i, size=(20, 7)) + 1).astype(np.int32)
+        excl = (rng.poisson(mean_e, size=(20, 7)) + 1).astype(np.int64)
+        p, n_bad = ctx.chi2_pairs(incl, excl)
+        assert n_bad == 0
+        want = O.chi2_pairs(incl, excl)
+        ok = want > 1e-290
+        np.testing.assert_allclose(p[ok], want[ok], rtol=1e-8, atol=0)
+        assert (p[~ok] <= 1e-280).all()
+
+
+def test_rowstats_rejects_too_many_columns(ctx):
+    from splicedice_amd.engine import SdiceError
+    data = np.zeros((4, 1100), np.float32)
+    with pytest.raises(SdiceError):
+        ctx.rowstats(data, np.arange(1025))
+    with pytest.raises(SdiceError):
+        ctx.rowstats(data, np.array([1100]))
