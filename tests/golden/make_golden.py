@@ -122,6 +122,63 @@ def main():
         json.dump(banners, fh, indent=1)
     os.remove(manifest_abs)
 
+    # ------------------------------------------------------------------ quant, hand-made edge cases
+    # duplicate lines (last count wins), both strands on the same coordinates, strand '.', annotated
+    # junctions that bypass the filters, every filter failing once, SJ.out.tab strand 0 / non-canonical
+    # motifs / multimapped counts, chromosome names whose string order differs from numeric order, file
+    # types that contribute nothing (.bam, unknown) and a leafcutter file
+    edir = fresh(os.path.join(HERE, "quant_edge"))
+    ein = fresh(os.path.join(edir, "inputs"))
+    sb = "e:1.50:1.20;o:20;m:GT_AG"
+    edge_files = {
+        "a.junc.bed": [
+            f"chr2\t100\t300\t{sb};a:?\t12\t+", f"chr2\t100\t300\t{sb};a:?\t3\t+",
+            f"chr10\t150\t400\t{sb};a:?\t9\t-", f"chr10\t150\t400\t{sb};a:?\t9\t+",
+            f"chrX\t50\t60000\t{sb};a:?\t20\t+", "chr2\t250\t500\te:0.50:1.20;o:20;m:GT_AG;a:?\t30\t+",
+            "chr2\t260\t520\te:1.50:1.20;o:3;m:GT_AG;a:?\t30\t+", "chr2\t270\t530\te:0.10:0.10;o:1;m:GT_AG;a:GENE1\t2\t+",
+            f"chr2\t280\t540\t{sb};a:?\t7\t.", f"chrM\t10\t200\t{sb};a:?\t8\t-", f"chr2\t290\t300\t{sb};a:?\t40\t+",
+            f"chr1\t5\t120\t{sb};a:?\t5\t+", f"chr1\t60\t200\t{sb};a:?\t6\t+", f"chr1\t120\t180\t{sb};a:?\t7\t+",
+            f"chr1\t200\t260\t{sb};a:?\t8\t+"],
+        "b.SJ.out.tab": [
+            "chr2\t101\t300\t1\t1\t0\t4\t3\t30", "chr2\t271\t530\t1\t1\t1\t10\t0\t20", "chr10\t151\t400\t2\t2\t0\t6\t0\t25",
+            "chr10\t151\t400\t0\t1\t0\t50\t0\t25", "chr2\t301\t900\t1\t0\t0\t50\t0\t25", "chr2\t301\t900\t1\t3\t0\t50\t0\t25",
+            "chrX\t1001\t2000\t2\t2\t1\t0\t9\t12", "chr1\t61\t200\t1\t1\t0\t2\t1\t12", "chr1\t6\t120\t1\t1\t0\t50\t50\t40"],
+        "c.plain.bed": [
+            "chr2\t100\t300\tj1\t6\t+", "chr2\t100\t300\tj1\t0\t+", "chr10\t150\t400\tj2\t5\t-", "chr3\t10\t20\tj3\t100\t+",
+            "chr2\t400\t700\tj4\t4\t+", "chr2\t400\t700\tj5\t8\t-", "chr1\t120\t180\tj6\t11\t+"],
+        "d.bam": [],
+        "e.leafcutter.junc": ["chr2\t400\t700\tclu_1\t9\t+", "chrX\t1000\t2000\tclu_2\t5\t-", "chr1\t200\t260\tclu_3\t1\t+"],
+        "f.counts.txt": ["whatever\t1\t2"],
+    }
+    for fname, lines in edge_files.items():
+        with open(os.path.join(ein, fname), "w") as fh:
+            fh.write("".join(line + "\n" for line in lines))
+    with open(os.path.join(edir, "manifest.rel.tsv"), "w") as fh:
+        for i, fname in enumerate(edge_files):
+            fh.write(f"s{i}\t{fname}\tm{i}\t{'A' if i < 3 else 'B'}\n")
+    manifest_abs = os.path.join(edir, "_manifest_abs.tmp")
+    with open(manifest_abs, "w") as fh:
+        for i, fname in enumerate(edge_files):
+            fh.write(f"s{i}\t{os.path.join(ein, fname)}\tm{i}\t{'A' if i < 3 else 'B'}\n")
+    edge_variants = {
+        "default": dict(),
+        "nomulti_lowcov": dict(noMultimap=True, lowCoverageNan=True, minUnique=6, drim=True),
+        "short": dict(minLength=5, maxLength=100000, minOverhang=1, minEntropy=0.05, minUnique=1),
+    }
+    for vname, over in edge_variants.items():
+        out = fresh(os.path.join(edir, f"expected_{vname}"))
+        args = ns(manifest=manifest_abs, output_prefix=os.path.join(out, "out"),
+                  maxLength=50000, minLength=50, minOverhang=5, drim=False, noMultimap=False,
+                  filter="gtag_only", minUnique=5, lowCoverageNan=False, minEntropy=1)
+        for k, v in over.items():
+            setattr(args, k, v)
+        SD.Sample.sampleList = []
+        SD.Sample.groups = {}
+        quiet(SD.run_with, args)
+        with open(os.path.join(out, "args.json"), "w") as fh:
+            json.dump(over, fh)
+    os.remove(manifest_abs)
+
     # ------------------------------------------------------------------ counts_to_ps
     cdir = fresh(os.path.join(HERE, "counts_to_ps"))
     base = os.path.join(qdir, "expected_default", "out")

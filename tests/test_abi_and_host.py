@@ -198,3 +198,37 @@ def test_shard_plan_clean_cuts_and_halo():
     assert plan[1]["ext_lo"] == 99 and plan[1]["ext_hi"] == 201
     rp, cl = shard.local_csr(row_ptr, col, plan[1])
     assert rp.size == 103 and cl.min() >= 0 and cl.max() <= 101
+
+
+@pytest.mark.parametrize("variant", ["default", "nomulti_lowcov", "short"])
+def test_quant_edge_cases_host_side(golden_dir, tmp_path, variant):
+    """the hand-made edge-case inputs (tests/golden/quant_edge): the Python restatement of the parsing
+    rules AND the library's C++ parser + union + lookup give the reference's junction list and counts"""
+    import json
+    from splicedice_amd import juncio, quant, textio
+    qdir = os.path.join(golden_dir, "quant_edge")
+    manifest_path = tmp_path / "manifest.tsv"
+    with open(os.path.join(qdir, "manifest.rel.tsv")) as src, open(manifest_path, "w") as dst:
+        for line in src:
+            row = line.rstrip("\n").split("\t")
+            row[1] = os.path.join(qdir, "inputs", row[1])
+            dst.write("\t".join(row) + "\n")
+    exp = os.path.join(qdir, f"expected_{variant}")
+    args = _quant_args(**json.load(open(os.path.join(exp, "args.json"))))
+    manifest = quant.parse_manifest(str(manifest_path))
+    assert [s.type for s in manifest] == ["splicedicebed", "SJ", "bed", "bam", "leafcutter", "unknown"]
+    bed = [ln.split("\t")[3] for ln in open(os.path.join(exp, "out_junctions.bed"))]
+    with open(os.path.join(exp, "out_inclusionCounts.tsv")) as fh:
+        fh.readline()
+        want_counts = [line.rstrip("\n").split("\t")[1:] for line in fh]
+    # (1) Python restatement
+    junctions = sorted(quant.get_all_junctions(manifest, args))
+    assert [textio.junction_name(j) for j in junctions] == bed
+    counts, _ = quant.get_junction_counts(manifest, {j: i for i, j in enumerate(junctions)}, args)
+    assert [[str(int(x)) for x in row] for row in counts] == want_counts
+    # (2) C++ parser, host union, C++ row lookup
+    names, junc, parsed = juncio.ingest(manifest, args, None)
+    got_names = [f"{names[c]}:{l}-{r}:{'+-'[s]}" for c, l, r, s in zip(*junc)]
+    assert got_names == bed
+    counts2, _ = juncio.gather_counts(manifest, parsed, junc, args)
+    assert [[str(int(x)) for x in row] for row in counts2] == want_counts
