@@ -113,7 +113,7 @@ __device__ __forceinline__ float div_small_ints(float a, float t) {
 // Fast item: every neighbour offset comes from the LDS stage and lies inside the staged window,
 // the tile's bound keeps incl + excl < 2^24 -> 32-bit sums, float32 quotient.  Returns false
 // (nothing stored) as soon as a neighbour is outside the window; the caller then runs ps_item_slow.
-template <int VEC, bool WEXCL, bool WPS>
+template <int VEC, bool WEXCL, bool WPS, bool CHECK>
 __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB, const int* colL, int k0, int k1,
                                              int cbytes, int own_off, int64_t out_index, int zero_off) {
     typedef typename Vt<VEC>::I VI;
@@ -133,10 +133,12 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
         for (int u = 0; u < GB; ++u) raw[u] = colL[k + u];
 #pragma unroll
         for (int u = 0; u < GB; ++u) off[u] = (k + u < k1) ? raw[u] : zero_off;
-        int mn = off[0];
+        if (CHECK) {      // (a tile whose staged neighbours all lie inside the window skips this)
+            int mn = off[0];
 #pragma unroll
-        for (int u = 1; u < GB; ++u) mn = min(mn, off[u]);
-        if (mn < 0) return false;
+            for (int u = 1; u < GB; ++u) mn = min(mn, off[u]);
+            if (mn < 0) return false;
+        }
         VI v[GB];
 #pragma unroll
         for (int u = 0; u < GB; ++u) v[u] = *reinterpret_cast<const VI*>(tileB + off[u] + cbytes);
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     const int slo = (int)max((int64_t)0, r0 - a.halo);
     const int shi = (int)min(a.n, r0 + nr + a.halo);
     const int wrows = shi - slo;
-    if (tid < 2) red[tid] = 0u;
+    if (tid < 3) red[tid] = 0u;                 // [0] max count, [1] max degree, [2] a staged neighbour is outside the window
     for (int i = tid; i < a.chunk_cols; i += T) tileL[(size_t)win_cap * a.chunk_cols + i] = 0;
     const int zero_off = win_cap * a.chunk_cols * 4;
 
@@ -290,11 +292,14 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     if (tid + T <= nr) rpL[tid + T] = (int)(rp_mine[1] - kbase);
     for (int i = tid + 2 * T; i <= nr; i += T) rpL[i] = (int)(a.row_ptr[r0 + i] - kbase);
     if (col_in_lds) {
+        bool outside = false;
         for (int k = tid; k < (int)nk; k += T) {
             const int j = a.col[kbase + k];
             const unsigned rel = (unsigned)(j - slo);
+            outside = outside || rel >= (unsigned)wrows;
             colL[k] = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
         }
+        if (__ballot(outside) != 0ull && (tid & 63) == 0) atomicOr(&red[2], 1u);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o));
@@ -308,6 +313,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     const unsigned tile_cmax = red[0], tile_dmax = red[1];
     const unsigned thr = 0xFFFFFFu / (tile_dmax + 1u);   // per-count bound keeping incl+excl < 2^24
     const bool fast = tile_cmax <= thr && col_in_lds;     // block-uniform
+    const bool all_in = red[2] == 0u;                     // block-uniform: no per-batch window check needed
 
     // ---- per (row, vector) item: gather neighbours from LDS, divide, store
     {
@@ -322,7 +328,8 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
             const int own_off = (own_base + ri) * ldw * 4;
             bool done = false;
             if (fast)
-                done = ps_item_fast<VEC, WEXCL, WPS>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
+                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
+                              : ps_item_fast<VEC, WEXCL, WPS, true>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
             if (!done)
                 ps_item_slow<VEC, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
                                               own_off, o);
