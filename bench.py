@@ -134,7 +134,12 @@ class QuantWorkload:
         self.alg_bytes = 8.0 * n * s
 
     def step(self):
-        self.d_col, self.nnz = self.ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr)
+        # the first call is synchronous (it sizes the neighbour-list buffer and reports nnz); after that
+        # the whole chain -- sort, row order, lists, PS -- is enqueued without a host round trip, and
+        # validation / capacity errors of the clustering surface at the next sync (sdice.h)
+        d_col, nnz = self.ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr, sync=not self.nnz)
+        if nnz is not None:
+            self.d_col, self.nnz = d_col, nnz
         self.ctx.ps_dev(self.d_counts, self.d_row_ptr, self.d_col, None, self.d_ps)
 
     def describe(self):

@@ -60,7 +60,8 @@ int sdice_dmemset(sdice_ctx* ctx, void* dptr, int value, int64_t bytes);
 /* ---- clustering: replaces SPLICEDICE.getClusters (SPLICEDICE.py:230-255), its twin
  *      counts_to_ps.determine_clusters (counts_to_ps.py:16-41) and the junctionIndex
  *      sort (SPLICEDICE.py:96).
- *  in : n junctions as parallel arrays, any order, all distinct.
+ *  in : n junctions as parallel arrays, any order, all distinct (a duplicate is reported as
+ *       SDICE_ERR_ARG: the reference holds the junctions in a set / dict, SPLICEDICE.py:156).
  *       chrom_rank = dense rank of the chromosome name under Python string sort,
  *       0 <= left <= right < 2^31, strand 0 = '+', 1 = '-'.
  *  out: row_of[n]   output row of input junction i = its rank in
@@ -77,9 +78,20 @@ int sdice_cluster(sdice_ctx* ctx, int64_t n, const int32_t* chrom_rank, const in
                   const int32_t* right, const int8_t* strand,
                   int32_t* row_of, int64_t* row_ptr, int64_t* nnz);
 int sdice_cluster_col(sdice_ctx* ctx, int32_t* col, int64_t capacity);
+/* Device variant.  nnz != NULL: synchronous on return (*nnz = list length; invalid or duplicate
+ * junctions are reported here).  nnz == NULL: ASYNCHRONOUS -- the whole chain (sort, row order,
+ * lists) is enqueued with no host round trip, so that a dependent sdice_ps_dev can be enqueued right
+ * behind it; validation results, nnz and the list capacity check are then reported by the next
+ * sdice_sync / sdice_cluster_status / sdice_cluster_col_dev(nnz != NULL) (deferred-error semantics,
+ * as for asynchronous HIP work).  A chain that failed leaves row_ptr all zero, so dependent launches
+ * stay in bounds.  The list buffer holds at least 16 entries per junction; one synchronous call sizes
+ * it for denser data. */
 int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom_rank,
                       const int32_t* d_left, const int32_t* d_right, const int8_t* d_strand,
-                      int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz /* host out, may be NULL; the call synchronises to size col */);
+                      int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz /* host out, may be NULL */);
+/* resolves a pending asynchronous sdice_cluster_dev (synchronises); nnz / reach (largest
+ * |row(neighbour) - row|) may be NULL */
+int sdice_cluster_status(sdice_ctx* ctx, int64_t* nnz, int32_t* reach);
 int sdice_cluster_col_dev(sdice_ctx* ctx, const int32_t** d_col, int64_t* nnz);
 
 /* ---- PS: replaces SPLICEDICE.calculatePsi (SPLICEDICE.py:297-310), counts_to_ps

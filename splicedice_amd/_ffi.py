@@ -36,6 +36,7 @@ SIGNATURES = {
     "sdice_cluster_col": [ctxp, vp, C.c_int64],
     "sdice_cluster_dev": [ctxp, C.c_int64, vp, vp, vp, vp, vp, vp, c_i64p],
     "sdice_cluster_col_dev": [ctxp, C.POINTER(vp), c_i64p],
+    "sdice_cluster_status": [ctxp, c_i64p, C.POINTER(C.c_int32)],
     "sdice_ps": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
     "sdice_ps_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
     "sdice_mark_low": [ctxp, C.c_int64, vp, vp, C.c_int64],

@@ -313,9 +313,10 @@ inline int bits_for(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return 
 
 }  // namespace
 
-extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left,
-                                 const int32_t* d_right, const int8_t* d_strand, int32_t* d_row_of,
-                                 int64_t* d_row_ptr, int64_t* nnz_out) {
+// The generic path (any n < 2^31, any field widths); sdice_cluster_dev (cluster_fast.hip) takes it
+// for more than 8 M junctions, when asked to by parameter and as its fallback.
+int sd_cluster_legacy(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left, const int32_t* d_right,
+                      const int8_t* d_strand, int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz_out) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
     SD_HIP(hipSetDevice(ctx->device));
@@ -477,9 +478,12 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     return SDICE_OK;
 }
 
+int sd_cluster_resolve(sdice_ctx* ctx);
+
 extern "C" int sdice_cluster_col_dev(sdice_ctx* ctx, const int32_t** d_col, int64_t* nnz) {
     SD_ARG(ctx && d_col, "bad arguments");
     *d_col = ctx->d_col;
+    if (nnz) SD_TRY(sd_cluster_resolve(ctx));      // (an asynchronous clustering learns its nnz here)
     if (nnz) *nnz = ctx->nnz;
     return SDICE_OK;
 }
@@ -517,6 +521,7 @@ extern "C" int sdice_cluster(sdice_ctx* ctx, int64_t n, const int32_t* chrom_ran
 
 extern "C" int sdice_cluster_col(sdice_ctx* ctx, int32_t* col, int64_t capacity) {
     SD_ARG(ctx, "ctx is NULL");
+    SD_TRY(sd_cluster_resolve(ctx));
     SD_ARG(capacity >= ctx->nnz, "capacity smaller than nnz");
     if (ctx->nnz == 0) return SDICE_OK;
     SD_ARG(col, "col is NULL");

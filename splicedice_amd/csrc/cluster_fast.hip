@@ -1,0 +1,891 @@
+// K1 + K2, fast path: junction sort and overlap lists in FOUR kernels, no host round trip.
+//
+// Replaces SPLICEDICE.getClusters (SPLICEDICE.py:230-255; twin counts_to_ps.py:16-41) and the
+// junctionIndex sort (SPLICEDICE.py:96), like cluster.hip (which stays as the generic path for more
+// than 8 M junctions and as the fallback).  Reference semantics kept: two junctions of one
+// chromosome+strand are neighbours iff their closed intervals overlap (prior.right >= cur.left, :250);
+// output rows are in (chrom, left, right, strand) order (:96); the list of a junction holds the
+// earlier junctions of the (chrom, strand, left, right) sweep most recent first, then the later ones
+// in sweep order.
+//
+// Formulation.  Within one chromosome+strand the sweep order and the row order agree (both are
+// (left, right)), so ONE sort into ROW order is enough: the earlier neighbours of row r are the rows
+// q < r of its chromosome with the same strand and right_q >= left_r, visited downwards; the later
+// ones are the rows q > r with the same strand and left_q <= right_r, visited upwards; rows of the
+// other strand that lie in between are stepped over.
+//
+//   sample_rank_kernel     ranks of a regular (jittered) sample of 8 keys per bucket by brute force
+//                          (every sample key against every other, 256 x 256 per workgroup)
+//   bucket_scatter_kernel  every 8th ranked sample key is a splitter; a tile of keys is classified by
+//                          binary search over the splitters in LDS, counted per bucket in LDS, and
+//                          placed into fixed-capacity bucket slots in HBM (one global atomic per
+//                          (tile, bucket)); validates the input, takes the maximum junction length
+//   bucket_sort_kernel     one workgroup per bucket (mean 2048 keys): bitonic sort of 16-byte
+//                          {chrom, left, right<<1|strand, input index} elements in LDS (buckets
+//                          beyond the LDS capacity are sorted in place in HBM by the same code);
+//                          writes the row-order arrays, row_of, and 64-row maxima of `right`
+//   neighbours_kernel      one tile of rows per workgroup: window of the row arrays in LDS, count
+//                          walk, workgroup scan, decoupled look-back over the tiles for the global
+//                          offset (8-byte {flag, value} granules, agent-scope relaxed atomics),
+//                          fill walk into an LDS stage, contiguous stores of row_ptr and col
+//
+// The backward walk ends at the first row whose left + (maximum junction length) is below the
+// target and skips 64-row blocks whose maximum `right` is below it.
+//
+// Nothing is read back by the host inside the chain: validation results, the total list length and
+// the neighbour reach live in a device status block that is fetched when the caller asks for nnz (or
+// at the next sdice_sync / sdice_cluster_status); a failed chain leaves row_ptr all zero (safe for a
+// dependent PS launch) and the failure is reported then.
+#include "common.h"
+
+int sd_cluster_legacy(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left, const int32_t* d_right,
+                      const int8_t* d_strand, int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz_out);
+
+namespace {
+
+constexpr int SPB = 8;                 // sample keys per bucket
+constexpr int BUCKET_MEAN = 2048;      // keys per bucket (mean)
+constexpr int MAX_BUCKETS = 4096;      // splitters + per-bucket counters must fit LDS of the scatter kernel
+constexpr int SLOT_FACTOR = 8;         // bucket slot capacity in HBM = 8 x mean
+constexpr int64_t FAST_MAX_N = (int64_t)MAX_BUCKETS * BUCKET_MEAN;
+
+enum : unsigned long long { ST_INVALID = 1, ST_SLOT_OVERFLOW = 2, ST_DUP = 4, ST_COL_OVERFLOW = 8, ST_LOOKBACK = 16 };
+// status block (uint64 words)
+constexpr int SB_FLAGS = 0, SB_NNZ = 2, SB_MAXLEN = 32, SB_REACH = 64, SB_WORDS = 96;
+constexpr int SB_SLOTS = 32;
+
+struct FastArgs {
+    const int32_t* chrom; const int32_t* left; const int32_t* right; const int8_t* strand;
+    int64_t n;
+    int B;                 // buckets
+    int S;                 // sample keys (SPB * B, 0 when B == 1)
+    int64_t slot_cap;      // elements per bucket slot
+    int lds_cap;           // elements the sort kernel may hold in LDS
+    unsigned long long* sb;   // status block
+    uint32_t* rank;        // [S]
+    uint64_t* spl;         // [B] splitters (chrom << 32 | left)
+    uint32_t* cursor;      // [B]
+    uint4* slots;          // [B * slot_cap]
+    uint32_t* rowC; uint32_t* rowL; uint32_t* rowR2;   // row-order arrays [n]
+    uint32_t* bmax64;      // [ceil(n/64)] max right per 64 rows
+    unsigned long long* tile_state;   // look-back granules of the neighbour kernel
+    int32_t* row_of; int64_t* row_ptr; int32_t* col; int64_t col_cap;
+    int ablate;            // timing experiments only (param cluster.ablate): results are wrong when set
+};
+
+__device__ __forceinline__ bool key_less(uint32_t ac, uint32_t al, uint32_t ar, uint32_t bc, uint32_t bl, uint32_t br) {
+    return ac < bc || (ac == bc && (al < bl || (al == bl && ar < br)));
+}
+__device__ __forceinline__ bool elem_less(const uint4& a, const uint4& b) { return key_less(a.x, a.y, a.z, b.x, b.y, b.z); }
+
+__device__ __forceinline__ int64_t sample_pos(int64_t i, int64_t n, int64_t S) {
+    const int64_t stride = n / S;                              // >= 1: S <= n / 128 by construction
+    const uint64_t h = ((uint64_t)i * 0x9E3779B97F4A7C15ull) >> 33;
+    return i * stride + (int64_t)(h % (uint64_t)stride);
+}
+
+// ------------------------------------------------------------------ 1. ranks of the sample keys
+// Sample keys and splitters are the 64-bit prefix (chrom << 32 | left) of the sort key: junctions that
+// share chromosome and left end always land in one bucket, and a key comparison is one instruction.
+__device__ __forceinline__ uint64_t sample_key(const FastArgs& a, int64_t i) {
+    const int64_t p = sample_pos(i, a.n, a.S);
+    return ((uint64_t)(uint32_t)a.chrom[p] << 32) | (uint64_t)(uint32_t)a.left[p];
+}
+
+__global__ void __launch_bounds__(256) sample_rank_kernel(FastArgs a) {
+    __shared__ uint64_t jk[256];
+    const int t = threadIdx.x;
+    // (the status block is first written by the next kernel: cleared here, no launch of its own)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t < SB_WORDS) a.sb[t] = 0ull;
+    const int64_t i = (int64_t)blockIdx.x * 256 + t, j = (int64_t)blockIdx.y * 256 + t;
+    jk[t] = j < a.S ? sample_key(a, j) : ~0ull;
+    const uint64_t ik = i < a.S ? sample_key(a, i) : 0ull;
+    __syncthreads();
+    // rank of key i among the sample = #{j : key_j < key_i, or equal and j < i}; j runs over this block's 256 keys
+    const int64_t j0 = (int64_t)blockIdx.y * 256;
+    const int64_t split = i - j0;                       // j0 + q < i  <=>  q < split
+    uint32_t cnt = 0;
+#pragma unroll 16
+    for (int q = 0; q < ((a.ablate & 8) ? 0 : 256); ++q) {
+        const uint64_t k = jk[q];
+        cnt += (k < ik || (k == ik && q < split)) ? 1u : 0u;
+    }
+    if (i < a.S && cnt) atomicAdd(&a.rank[i], cnt);
+}
+
+// every SPB-th sample key in rank order is a splitter
+__global__ void __launch_bounds__(256) splitter_kernel(FastArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.S) return;
+    const uint32_t rk = a.rank[q];
+    if (rk != 0 && rk % SPB == 0) a.spl[rk / SPB - 1] = sample_key(a, q);      // slots 0 .. B-2
+}
+
+// ------------------------------------------------------------------ 2. classify + scatter into slots
+constexpr int SC_KPT = 4;
+template <int T>
+__global__ void __launch_bounds__(T) bucket_scatter_kernel(FastArgs a) {
+    extern __shared__ uint64_t sm64[];
+    const int B = a.B;
+    uint64_t* spl = sm64;                                        // [B] (B-1 used)
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sm64 + B);       // [B]
+    uint32_t* base = cnt + B;                                    // [B]
+    __shared__ uint32_t wmax[T / 64];
+    __shared__ uint32_t s_bad, s_over;
+    const int t = threadIdx.x;
+    if (t == 0) { s_bad = 0; s_over = 0; }
+    for (int b = t; b < B; b += T) { spl[b] = b < B - 1 ? a.spl[b] : ~0ull; cnt[b] = 0; }
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * T * SC_KPT;
+    uint32_t kc[SC_KPT], kl[SC_KPT], kr[SC_KPT], bk[SC_KPT], lr[SC_KPT];
+    uint32_t maxlen = 0, bad = 0;
+#pragma unroll
+    for (int q = 0; q < SC_KPT; ++q) {
+        const int64_t i = tile0 + q * T + t;
+        bk[q] = 0xffffffffu;
+        kc[q] = kl[q] = kr[q] = lr[q] = 0;
+        if (i < a.n) {
+            const int32_t c = a.chrom[i], l = a.left[i], r = a.right[i];
+            const int st = a.strand[i];
+            if (l < 0 || r < l || c < 0 || (st != 0 && st != 1)) bad = 1;
+            else maxlen = max(maxlen, (uint32_t)(r - l));
+            kc[q] = (uint32_t)c; kl[q] = (uint32_t)l; kr[q] = ((uint32_t)r << 1) | (uint32_t)(st & 1);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SC_KPT; ++q) {
+        if (tile0 + q * T + t < a.n) {
+            const uint64_t k = ((uint64_t)kc[q] << 32) | kl[q];
+            int lo = 0, hi = B - 1;                            // bucket = number of splitters <= key
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (spl[mid] <= k) lo = mid + 1; else hi = mid;
+            }
+            bk[q] = (uint32_t)lo;
+            lr[q] = atomicAdd(&cnt[lo], 1u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    if ((t & 63) == 0) wmax[t >> 6] = maxlen;
+    if (bad) s_bad = 1;
+    __syncthreads();
+    for (int b = t; b < B; b += T) {
+        const uint32_t c = cnt[b];
+        base[b] = (c && !(a.ablate & 32)) ? atomicAdd(&a.cursor[b], c) : 0u;
+    }
+    if (t == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < T / 64; ++w) m = max(m, wmax[w]);
+        if (m) atomicMax(&a.sb[SB_MAXLEN + (blockIdx.x % SB_SLOTS)], (unsigned long long)m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SC_KPT; ++q) {
+        if (bk[q] == 0xffffffffu) continue;
+        const int64_t i = tile0 + q * T + t;
+        const uint64_t pos = (uint64_t)base[bk[q]] + lr[q];
+        if (a.ablate & 16) continue;
+        if (pos < (uint64_t)a.slot_cap) a.slots[(int64_t)bk[q] * a.slot_cap + (int64_t)pos] = make_uint4(kc[q], kl[q], kr[q], (uint32_t)i);
+        else s_over = 1;
+    }
+    __syncthreads();
+    if (t == 0 && (s_bad | s_over))
+        atomicOr(&a.sb[SB_FLAGS], (s_bad ? (unsigned long long)ST_INVALID : 0ull) | (s_over ? (unsigned long long)ST_SLOT_OVERFLOW : 0ull));
+}
+
+// ------------------------------------------------------------------ 3. per-bucket sort, row arrays
+__device__ __forceinline__ void cmpswap(uint4* buf, int lo, int hi) {
+    const uint4 x = buf[lo], y = buf[hi];
+    if (elem_less(y, x)) { buf[lo] = y; buf[hi] = x; }
+}
+__device__ __forceinline__ void cmpswap(uint64_t* buf, int lo, int hi) {
+    const uint64_t x = buf[lo], y = buf[hi];
+    buf[lo] = y < x ? y : x;                 // unconditional: no exec-mask juggling around two LDS stores
+    buf[hi] = y < x ? x : y;
+}
+
+// Bitonic network in its "flip + disperse" form: every comparator puts the smaller element at the
+// lower index, so positions >= count (virtual +inf) never take part and P need not equal count.
+// With comparator c handled by thread c % T, a wave's 64 comparators of a flip with k <= 128 or of a
+// disperse with j <= 64 all lie inside one 128-element segment that belongs to that wave alone;
+// consecutive such steps need no workgroup barrier (LDS operations of one wave complete in order).
+template <bool WAVE_LOCAL_OK, typename E>
+__device__ __forceinline__ void bitonic_sort(E* buf, int count, int P, int t, int T) {
+    const int half = P >> 1;
+    bool prev_confined = false;
+    for (int k = 2; k <= P; k <<= 1) {
+        {
+            const bool confined = WAVE_LOCAL_OK && k <= 128;
+            if (confined && prev_confined) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+            prev_confined = confined;
+            const int hk = k >> 1, lg = __ffs(hk) - 1;
+            for (int c = t; c < half; c += T) {
+                const int off = c & (hk - 1);
+                const int b0 = (c >> lg) << (lg + 1);
+                const int lo = b0 + off, hi = b0 + k - 1 - off;
+                if (hi < count) cmpswap(buf, lo, hi);
+            }
+        }
+        for (int j = k >> 2; j >= 1; j >>= 1) {
+            const bool confined = WAVE_LOCAL_OK && j <= 64;
+            if (confined && prev_confined) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+            prev_confined = confined;
+            for (int c = t; c < half; c += T) {
+                const int off = c & (j - 1);
+                const int lo = ((c - off) << 1) + off, hi = lo + j;
+                if (hi < count) cmpswap(buf, lo, hi);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+constexpr int SORT_T = 1024;
+constexpr int SORT_WAVES = SORT_T / 64;
+constexpr int RDX_CAP = 8192;                    // packed 64-bit keys a bucket may hold in LDS
+constexpr int RDX_IDX_BITS = 13;                 // slot index of an element rides in the low bits of its key
+constexpr int SORT_LDS_ELEMS = 4096;             // 16-byte elements of the unpacked fallback (same LDS)
+constexpr size_t SORT_LDS_BYTES = (size_t)RDX_CAP * 8;     // 64 KB: two workgroups per CU
+static_assert(SORT_LDS_BYTES >= (size_t)SORT_LDS_ELEMS * 16, "unpacked fallback must fit");
+
+__device__ __forceinline__ int bits_u32(uint32_t v) { return v ? 32 - __clz(v) : 0; }
+
+__global__ void __launch_bounds__(SORT_T, 8) bucket_sort_kernel(FastArgs a) {      // 64 VGPRs: two workgroups per CU
+    extern __shared__ uint4 lds_elems[];
+    __shared__ unsigned long long wsum[SORT_WAVES];
+    __shared__ uint32_t red[5][SORT_WAVES];
+    __shared__ uint32_t s_dup;
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, w = t >> 6;
+    if (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW)) return;      // uniform: written by the previous kernel
+    const int count = (int)a.cursor[b];
+    // first row of this bucket = number of keys in the buckets before it
+    unsigned long long part = 0;
+    for (int i = t; i < b; i += SORT_T) part += a.cursor[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) wsum[w] = part;
+    if (t == 0) s_dup = 0;
+    __syncthreads();
+    int64_t start = 0;
+    for (int k = 0; k < SORT_WAVES; ++k) start += (int64_t)wsum[k];
+    if (count == 0) return;
+    uint4* src = a.slots + (int64_t)b * a.slot_cap;
+
+    // ---- choose the path: packed local keys + LDS radix, LDS bitonic, or in-place bitonic in HBM
+    int total_bits = 99, bl = 0, bn = 0;
+    uint32_t cmin = 0, lmin = 0;
+    const bool small = count <= RDX_CAP && count <= a.lds_cap;
+    if (small) {
+        uint32_t c0 = 0xffffffffu, c1 = 0, l0 = 0xffffffffu, l1 = 0, n1 = 0;
+        for (int i = t; i < count; i += SORT_T) {
+            const uint4 e = src[i];
+            c0 = min(c0, e.x); c1 = max(c1, e.x); l0 = min(l0, e.y); l1 = max(l1, e.y); n1 = max(n1, (e.z >> 1) - e.y);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c0 = min(c0, (uint32_t)__shfl_xor((int)c0, o)); c1 = max(c1, (uint32_t)__shfl_xor((int)c1, o));
+            l0 = min(l0, (uint32_t)__shfl_xor((int)l0, o)); l1 = max(l1, (uint32_t)__shfl_xor((int)l1, o));
+            n1 = max(n1, (uint32_t)__shfl_xor((int)n1, o));
+        }
+        if (lane == 0) { red[0][w] = c0; red[1][w] = c1; red[2][w] = l0; red[3][w] = l1; red[4][w] = n1; }
+        __syncthreads();
+        for (int k = 0; k < SORT_WAVES; ++k) {
+            c0 = min(c0, red[0][k]); c1 = max(c1, red[1][k]); l0 = min(l0, red[2][k]); l1 = max(l1, red[3][k]);
+            n1 = max(n1, red[4][k]);
+        }
+        cmin = c0; lmin = l0;
+        bl = bits_u32(l1 - l0); bn = bits_u32(n1);
+        total_bits = bits_u32(c1 - c0) + bl + bn + 1;
+    }
+    uint32_t dup = 0;
+    // rows, row_of, 64-row maxima for the sorted element i (fetched by `get`); `same_as_next` flags a duplicate key
+    auto emit_all = [&](auto get) {
+        for (int i0 = 0; i0 < count; i0 += SORT_T) {
+            const int i = i0 + t;
+            const bool act = i < count;
+            uint32_t rr = 0, blk = 0xffffffffu;
+            if (act) {
+                const uint4 e = get(i);
+                const int64_t r = start + i;
+                a.rowC[r] = e.x; a.rowL[r] = e.y; a.rowR2[r] = e.z;
+                a.row_of[e.w] = (int32_t)r;
+                rr = e.z >> 1;
+                blk = (uint32_t)(r >> 6);
+            }
+            // 64 consecutive rows touch at most two 64-row blocks: one maximum for each
+            const uint32_t blk0 = (uint32_t)__shfl((int)blk, 0);
+            uint32_t m0 = (act && blk == blk0) ? rr : 0u, m1 = (act && blk != blk0) ? rr : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o));
+                m1 = max(m1, (uint32_t)__shfl_xor((int)m1, o));
+            }
+            if (lane == 0 && blk0 != 0xffffffffu) {
+                if (m0) atomicMax(&a.bmax64[blk0], m0);
+                if (m1) atomicMax(&a.bmax64[blk0 + 1], m1);
+            }
+        }
+    };
+    if (small && total_bits + RDX_IDX_BITS <= 64) {
+        uint64_t* kb0 = reinterpret_cast<uint64_t*>(lds_elems);
+        for (int i = t; i < count; i += SORT_T) {
+            const uint4 e = src[i];
+            uint64_t k = (((uint64_t)(e.x - cmin) << bl) | (uint64_t)(e.y - lmin)) << bn;
+            k = ((k | (uint64_t)((e.z >> 1) - e.y)) << 1) | (uint64_t)(e.z & 1u);
+            kb0[i] = (k << RDX_IDX_BITS) | (uint64_t)i;
+        }
+        // bitonic network on the packed keys: one LDS round trip per step, most steps wave-local.
+        // (An LSD radix with per-wave counters was measured at ~5 us per 9-bit pass -- four barriers
+        //  and a 8192-counter scan each -- against ~1 us per ten steps of this network.)
+        int P = 1;
+        while (P < count) P <<= 1;
+        if (P > 1 && !(a.ablate & 1)) bitonic_sort<true, uint64_t>(kb0, count, P, t, SORT_T); else __syncthreads();
+        const uint64_t* sorted = kb0;
+        for (int i = t; i + 1 < count; i += SORT_T)
+            if ((sorted[i] >> RDX_IDX_BITS) == (sorted[i + 1] >> RDX_IDX_BITS)) dup = 1;
+        if (!(a.ablate & 2)) emit_all([&](int i) { return src[sorted[i] & ((1u << RDX_IDX_BITS) - 1u)]; });
+    } else {
+        int P = 1;
+        while (P < count) P <<= 1;
+        uint4* buf;
+        if (count <= SORT_LDS_ELEMS && count <= a.lds_cap) {
+            for (int i = t; i < count; i += SORT_T) lds_elems[i] = src[i];
+            buf = lds_elems;
+            if (P > 1) bitonic_sort<true, uint4>(buf, count, P, t, SORT_T); else __syncthreads();
+        } else {
+            buf = src;                                         // rare: sorted in place in HBM
+            bitonic_sort<false, uint4>(buf, count, P, t, SORT_T);
+        }
+        for (int i = t; i + 1 < count; i += SORT_T) {
+            const uint4 e = buf[i], f = buf[i + 1];
+            if (f.x == e.x && f.y == e.y && f.z == e.z) dup = 1;
+        }
+        emit_all([&](int i) { return buf[i]; });
+    }
+    if (dup) s_dup = 1;
+    __syncthreads();
+    if (t == 0 && s_dup) atomicOr(&a.sb[SB_FLAGS], (unsigned long long)ST_DUP);
+}
+
+// ------------------------------------------------------------------ 4. neighbour lists
+constexpr unsigned long long LB_A = 1ull << 62, LB_P = 2ull << 62, LB_MASK = (1ull << 62) - 1;
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Exclusive prefix of `agg` over the tiles before `tile` (called by the 64 lanes of one wave).
+// Tile = workgroup id.  A workgroup publishes its aggregate before it waits for anything, and each
+// XCD starts its workgroups in increasing id order, so the smallest unfinished tile is always running
+// and every wait ends; HIP does not promise that order, hence the spin is bounded: a wait that
+// outlasts ~1 s gives up, flags ST_LOOKBACK (the chain's result is then discarded and the caller
+// falls back to the generic path) and the grid drains.
+__device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* state, int tile, unsigned long long agg,
+                                                                 int lane, unsigned long long* sb) {
+    if (lane == 0) st_agent(&state[tile], (tile == 0 ? LB_P : LB_A) | agg);
+    unsigned long long excl = 0;
+    int idx = tile - 1;
+    unsigned spins = 0;
+    while (idx >= 0) {
+        const int j = idx - lane;
+        const unsigned long long v = j >= 0 ? ld_agent(&state[j]) : LB_P;
+        const unsigned flag = (unsigned)(v >> 62);
+        const unsigned long long empty = __ballot(flag == 0u);
+        const unsigned long long pm = __ballot(flag == 2u);
+        const int first_p = pm ? __ffsll((long long)pm) - 1 : 64;
+        const unsigned long long need = first_p >= 63 ? ~0ull : ((1ull << (first_p + 1)) - 1ull);
+        if (empty & need) {
+            if (++spins > (1u << 21)) {
+                if (lane == 0) atomicOr(&sb[SB_FLAGS], (unsigned long long)ST_LOOKBACK);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        unsigned long long x = lane <= first_p ? (v & LB_MASK) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        excl += x;
+        if (first_p < 64) break;
+        idx -= 64;
+    }
+    if (lane == 0 && tile != 0) st_agent(&state[tile], LB_P | (excl + agg));
+    return excl;
+}
+
+// Tile of T rows per workgroup, tile = workgroup id (see lookback_exclusive).
+template <int T>
+struct NbCfg {
+    static constexpr int HB = 256;             // rows staged before the tile
+    static constexpr int HF = 128;             // rows staged after it
+    static constexpr int W = T + HB + HF;
+    static constexpr int STAGE = 12 * T;       // list entries staged in LDS per tile
+    static constexpr int KMAX = 16;            // entries a row keeps from its (single) walk, as 16-bit row distances
+    static constexpr int WIN_WORDS = 7 * W;    // cL (64 bit), R2, prefix max strand 0 / 1 (64 bit each)
+    static constexpr int UNION_WORDS = WIN_WORDS > STAGE ? WIN_WORDS : STAGE;
+};
+
+// walks outside the staged window (long junctions, dense loci, rows that redo their list): row arrays
+// from global memory, 64-row blocks without a reaching `right` skipped, end at left + maxlen < target
+template <class Emit>
+__device__ __forceinline__ void walk_back_global(const FastArgs& a, int q, uint32_t c, uint32_t l, uint32_t st, uint32_t maxlen,
+                                                 Emit emit) {
+    while (q >= 0) {
+        const uint32_t qc = a.rowC[q], ql = a.rowL[q], qr = a.rowR2[q];
+        if (qc != c || ql + maxlen < l) break;
+        if ((q & 63) == 63 && a.bmax64[q >> 6] < l) { q -= 64; continue; }
+        if ((qr & 1u) == st && (qr >> 1) >= l) emit(q);
+        --q;
+    }
+}
+template <class Emit>
+__device__ __forceinline__ void walk_fwd_global(const FastArgs& a, int q, int n, uint32_t c, uint32_t rgt, uint32_t st, Emit emit) {
+    while (q < n) {
+        const uint32_t qc = a.rowC[q], ql = a.rowL[q], qr = a.rowR2[q];
+        if (qc != c || ql > rgt) break;
+        if ((qr & 1u) == st) emit(q);
+        ++q;
+    }
+}
+
+template <int T>
+__global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a) {      // three workgroups per CU
+    typedef NbCfg<T> Cfg;
+    constexpr int W = Cfg::W, KMAX = Cfg::KMAX;
+    constexpr int EPT = (W + T - 1) / T;       // window elements per thread in the prefix-maximum scan
+    // the window, later the list stage:
+    //   cL[i]  = (chrom - chrom[window start]) << 32 | left      forward walks end at cL > (c << 32 | right)
+    //   wR[i]  = right << 1 | strand
+    //   pm0/1  = running maximum over the window rows <= i of strand 0 / 1 of  (chrom - ...) << 32 | right:
+    //            a backward walk for (c, left) ends at the first row with pm < (c << 32 | left) -- nothing
+    //            at or before it (of this chromosome and strand) reaches `left`
+    __shared__ __align__(16) uint32_t u_mem[Cfg::UNION_WORDS];
+    __shared__ int16_t tmp[(KMAX + 1) * T];     // (row KMAX is a dummy target for non-hits)
+    __shared__ uint32_t wsum[T / 64];
+    __shared__ unsigned long long wmax0[T / 64], wmax1[T / 64];
+    __shared__ uint32_t s_misc[4];             // [1] maxlen, [2] reach
+    __shared__ unsigned long long s_base;
+    unsigned long long* cL = reinterpret_cast<unsigned long long*>(u_mem);
+    unsigned long long* pm0 = cL + W;
+    unsigned long long* pm1 = pm0 + W;
+    uint32_t* wR = reinterpret_cast<uint32_t*>(pm1 + W);
+    int32_t* stage = reinterpret_cast<int32_t*>(u_mem);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int n = (int)a.n;
+    const int n_tiles = (n + T - 1) / T;
+    const int tile = blockIdx.x;
+    const int t0 = tile * T;
+    const int nr = min(T, n - t0);
+    if (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW | ST_DUP)) {
+        // failed chain: leave an all-zero row_ptr (every list empty) so that a dependent launch stays in bounds
+        if (t < nr) a.row_ptr[t0 + t] = 0;
+        if (t0 + t == 0) a.row_ptr[n] = 0;
+        return;
+    }
+    if (t == 0) s_misc[2] = 0;
+    if (t < 64) {
+        unsigned long long m = t < SB_SLOTS ? a.sb[SB_MAXLEN + t] : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(m, o); m = y > m ? y : m; }
+        if (t == 0) s_misc[1] = (uint32_t)m;
+    }
+    const int wlo = max(0, t0 - Cfg::HB), whi = min(n, t0 + nr + Cfg::HF);
+    const int wn = whi - wlo;
+    const uint32_t c0w = a.rowC[wlo];
+    const uint32_t l0w = a.rowL[wlo];
+    for (int i = t; i < wn; i += T) {
+        cL[i] = ((unsigned long long)(a.rowC[wlo + i] - c0w) << 32) | a.rowL[wlo + i];
+        wR[i] = a.rowR2[wlo + i];
+    }
+    __syncthreads();
+    const uint32_t maxlen = s_misc[1];
+    const int64_t cap = a.col_cap;
+    {
+        unsigned long long v0[EPT], v1[EPT], r0 = 0, r1 = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = t * EPT + e;
+            if (i < wn) {
+                const uint32_t r2 = wR[i];
+                const unsigned long long comp = (cL[i] & 0xffffffff00000000ull) | (r2 >> 1);
+                if (r2 & 1u) r1 = comp > r1 ? comp : r1; else r0 = comp > r0 ? comp : r0;
+            }
+            v0[e] = r0; v1[e] = r1;
+        }
+        unsigned long long x0 = r0, x1 = r1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long y0 = __shfl_up(x0, o), y1 = __shfl_up(x1, o);
+            if (lane >= o) { x0 = y0 > x0 ? y0 : x0; x1 = y1 > x1 ? y1 : x1; }
+        }
+        if (lane == 63) { wmax0[w] = x0; wmax1[w] = x1; }
+        __syncthreads();
+        unsigned long long p0 = __shfl_up(x0, 1), p1 = __shfl_up(x1, 1);      // exclusive over the threads before
+        if (lane == 0) { p0 = 0; p1 = 0; }
+        for (int k = 0; k < w; ++k) { p0 = wmax0[k] > p0 ? wmax0[k] : p0; p1 = wmax1[k] > p1 ? wmax1[k] : p1; }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = t * EPT + e;
+            if (i < wn) { pm0[i] = v0[e] > p0 ? v0[e] : p0; pm1[i] = v1[e] > p1 ? v1[e] : p1; }
+        }
+    }
+    __syncthreads();
+
+    const int r = t0 + t;
+    const int ri = r - wlo;
+    const bool act = t < nr;
+    unsigned long long own = 0;
+    uint32_t r2 = 0;
+    if (act) { own = cL[ri]; r2 = wR[ri]; }
+    const uint32_t l = (uint32_t)own, crel = (uint32_t)(own >> 32), c = crel + c0w;
+    const uint32_t rgt = r2 >> 1, st = r2 & 1u;
+    const unsigned long long tb = own;                                          // (chrom, left)
+    const unsigned long long tf = (own & 0xffffffff00000000ull) | rgt;          // (chrom, right)
+    // the window maxima decide the end of the backward walk iff no row before the window can reach `left`
+    const bool exact = wlo == 0 || crel != 0 || l0w + maxlen < l;
+
+    uint32_t deg = 0;
+    int far_b = r, far_f = r;
+    bool redo = false;                         // the 16-bit list of this row is incomplete
+    // rows reached outside the window (rare): distance may not fit 16 bits
+    auto emit_far = [&](int q) {
+        const int d = q - r;
+        if (deg < (uint32_t)KMAX) {
+            if (d >= -32768 && d <= 32767) tmp[deg * T + t] = (int16_t)d; else redo = true;
+        }
+        ++deg;
+        if (d < 0) far_b = q; else far_f = q;
+    };
+    if (act && !(a.ablate & 64)) {
+        // ---- earlier rows, most recent first.  The loops are written without conditional statements
+        //      (loads at a clamped index, a dummy 17th list row for the non-hits, two rows per trip):
+        //      as nested ifs they compiled to two serialised LDS round trips and ~25 exec-mask
+        //      instructions per row.
+        int16_t* mytmp = tmp + t;
+        auto take = [&](bool hit, int d, int q) {
+            const uint32_t slot = (hit & (deg < (uint32_t)KMAX)) ? deg : (uint32_t)KMAX;
+            mytmp[slot * T] = (int16_t)d;
+            deg += hit ? 1u : 0u;
+            return hit ? q : -1;
+        };
+        if (exact) {
+            const unsigned long long* pm = st ? pm1 : pm0;
+            int qi = ri - 1;
+            for (;;) {
+                const int q0 = max(qi, 0), q1 = max(qi - 1, 0);
+                const unsigned long long m0 = pm[q0], m1 = pm[q1];
+                const uint32_t x0 = wR[q0], x1 = wR[q1];
+                if (!((qi >= 0) & (m0 >= tb))) break;
+                // (pm >= target: row qi is of this chromosome)
+                const int f0 = take(((x0 & 1u) == st) & ((x0 >> 1) >= l), qi - ri, wlo + qi);
+                far_b = f0 >= 0 ? f0 : far_b;
+                --qi;
+                if (!((qi >= 0) & (m1 >= tb))) break;
+                const int f1 = take(((x1 & 1u) == st) & ((x1 >> 1) >= l), qi - ri, wlo + qi);
+                far_b = f1 >= 0 ? f1 : far_b;
+                --qi;
+            }
+            if (qi < 0 && wlo > 0) walk_back_global(a, wlo - 1, c, l, st, maxlen, emit_far);
+        } else {
+            walk_back_global(a, r - 1, c, l, st, maxlen, emit_far);
+        }
+        // ---- later rows in order
+        {
+            int qi = ri + 1;
+            const int last = wn - 1;
+            for (;;) {
+                const int q0 = min(qi, last), q1 = min(qi + 1, last);
+                const unsigned long long c0 = cL[q0], c1 = cL[q1];
+                const uint32_t x0 = wR[q0], x1 = wR[q1];
+                if (!((qi <= last) & (c0 <= tf))) break;
+                // (cL <= target behind row r: same chromosome)
+                const int f0 = take((x0 & 1u) == st, qi - ri, wlo + qi);
+                far_f = f0 >= 0 ? f0 : far_f;
+                ++qi;
+                if (!((qi <= last) & (c1 <= tf))) break;
+                const int f1 = take((x1 & 1u) == st, qi - ri, wlo + qi);
+                far_f = f1 >= 0 ? f1 : far_f;
+                ++qi;
+            }
+            if (qi > last && whi < n) walk_fwd_global(a, whi, n, c, rgt, st, emit_far);
+        }
+        if (deg > (uint32_t)KMAX) redo = true;
+    }
+    uint32_t reach = (uint32_t)max(r - far_b, far_f - r);
+    // ---- workgroup exclusive scan of the degrees, look-back for the global offset
+    uint32_t x = deg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) reach = max(reach, (uint32_t)__shfl_xor((int)reach, o));
+    if (lane == 63) wsum[w] = x;
+    if (lane == 0 && reach) atomicMax(&s_misc[2], reach);
+    __syncthreads();                           // (also: every walk over the window is done, the stage may overwrite it)
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < T / 64; ++k) { const uint32_t v = wsum[k]; if (k < w) wbase += v; total += v; }
+    const uint32_t loff = wbase + x - deg;
+    if (w == 0) {
+        const unsigned long long base = (a.ablate & 128) ? 0ull : lookback_exclusive(a.tile_state, tile, (unsigned long long)total, lane, a.sb);
+        if (lane == 0) {
+            s_base = base;
+            if (s_misc[2]) atomicMax(&a.sb[SB_REACH + (tile % SB_SLOTS)], (unsigned long long)s_misc[2]);
+        }
+    }
+    const bool staged = total <= (uint32_t)Cfg::STAGE;
+    if (staged && act && deg) {
+        if (!redo) {
+            for (uint32_t k = 0; k < deg; ++k) stage[loff + k] = r + (int)tmp[k * T + t];
+        } else {
+            uint32_t k = loff;
+            walk_back_global(a, r - 1, c, l, st, maxlen, [&](int q) { stage[k++] = q; });
+            walk_fwd_global(a, r + 1, n, c, rgt, st, [&](int q) { stage[k++] = q; });
+        }
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)s_base;
+    if (act) a.row_ptr[r] = min(base + (int64_t)loff, cap);
+    if (tile == n_tiles - 1 && t == 0) {
+        a.row_ptr[n] = min(base + (int64_t)total, cap);
+        a.sb[SB_NNZ] = (unsigned long long)(base + (int64_t)total);
+        if (base + (int64_t)total > cap) atomicOr(&a.sb[SB_FLAGS], (unsigned long long)ST_COL_OVERFLOW);
+    }
+    if (staged) {
+        for (uint32_t k = t; k < total; k += T)
+            if (base + k < cap) a.col[base + k] = stage[k];
+    } else if (act && deg) {                   // a very dense tile: straight to global memory
+        int64_t k = base + loff;
+        auto put = [&](int q) { if (k < cap) a.col[k] = q; ++k; };
+        walk_back_global(a, r - 1, c, l, st, maxlen, put);
+        walk_fwd_global(a, r + 1, n, c, rgt, st, put);
+    }
+}
+
+inline unsigned grid_for(int64_t n, int threads) { return (unsigned)sd_ceil_div(n, threads); }
+
+struct FastPlan {
+    FastArgs a;
+    size_t zero_bytes;     // the region cleared before every run (status block .. tile states)
+    void* zero_base;
+    size_t k4_zero_bytes;  // part of it needed again when only the neighbour kernel is re-run
+    int n_tiles;
+};
+
+constexpr int NB_T = 512;
+
+int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left, const int32_t* d_right,
+              const int8_t* d_strand, int32_t* d_row_of, int64_t* d_row_ptr, FastPlan& pl) {
+    FastArgs& a = pl.a;
+    a.chrom = d_chrom; a.left = d_left; a.right = d_right; a.strand = d_strand; a.n = n;
+    int64_t B = sd_ceil_div(n, BUCKET_MEAN);
+    if (B < 1) B = 1;
+    a.B = (int)B;
+    a.S = B > 1 ? (int)(B * SPB) : 0;
+    const int64_t mean = sd_ceil_div(n, B);
+    a.slot_cap = B > 1 ? (mean * SLOT_FACTOR < n ? mean * SLOT_FACTOR : n) : n;
+    int64_t lds_cap = ctx->param("cluster.lds_cap", 8192);      // (test knob: 0 = default; small values force the HBM sort)
+    if (lds_cap <= 0 || lds_cap > 8192) lds_cap = 8192;
+    if (lds_cap < 2) lds_cap = 2;
+    a.lds_cap = (int)lds_cap;
+    pl.n_tiles = (int)sd_ceil_div(n, NB_T);
+    const size_t nb64 = (size_t)sd_ceil_div(n, 64) + 2;
+    // The status block is a small persistent allocation of the context (an asynchronous call is
+    // resolved later, when the arena may already hold another call's scratch).
+    if (!ctx->cluster_sb) {
+        hipError_t e = hipMalloc((void**)&ctx->cluster_sb, (size_t)SB_WORDS * 8);
+        if (e != hipSuccess) {
+            sdice_set_error("sdice_cluster: hipMalloc of the status block failed: %s", hipGetErrorString(e));
+            return SDICE_ERR_NOMEM;
+        }
+    }
+    // zero region: [tile states] (needed by every neighbour run) then [cursor | rank | bmax64]
+    const size_t zk4 = (size_t)pl.n_tiles * 8;
+    const size_t zrest = (size_t)a.B * 4 + (size_t)(a.S + 4) * 4 + nb64 * 4;     // cursor | rank | bmax64
+    const size_t slots_bytes = (size_t)a.B * (size_t)a.slot_cap * 16;
+    const size_t total = zk4 + zrest + slots_bytes + (size_t)n * 12 + (size_t)a.B * 8 + 16 * 4096;
+    SD_TRY(ctx->arena.reserve(total, ctx->stream));
+    Arena& A = ctx->arena;
+    char* z = (char*)A.alloc(zk4 + zrest + 1024);
+    a.slots = (uint4*)A.alloc(slots_bytes);
+    a.rowC = (uint32_t*)A.alloc((size_t)n * 4);
+    a.rowL = (uint32_t*)A.alloc((size_t)n * 4);
+    a.rowR2 = (uint32_t*)A.alloc((size_t)n * 4);
+    a.spl = (uint64_t*)A.alloc((size_t)a.B * 8);
+    if (!z || !a.slots || !a.rowC || !a.rowL || !a.rowR2 || !a.spl) return SDICE_ERR_NOMEM;
+    pl.zero_base = z;
+    pl.k4_zero_bytes = zk4;
+    pl.zero_bytes = zk4 + zrest;
+    a.sb = (unsigned long long*)ctx->cluster_sb;
+    a.tile_state = (unsigned long long*)z;
+    a.cursor = (uint32_t*)(z + zk4);
+    a.rank = a.cursor + a.B;
+    a.bmax64 = a.rank + a.S + 4;
+    a.row_of = d_row_of; a.row_ptr = d_row_ptr;
+    a.ablate = (int)ctx->param("cluster.ablate", 0);
+    return SDICE_OK;
+}
+
+int launch_neighbours(sdice_ctx* ctx, FastPlan& pl) {
+    pl.a.col = ctx->d_col;
+    pl.a.col_cap = ctx->col_cap;
+    SD_LAUNCH(ctx, "neighbours_kernel", (neighbours_kernel<NB_T>), dim3((unsigned)pl.n_tiles), dim3(NB_T), 0, pl.a);
+    return SDICE_OK;
+}
+
+int ensure_col(sdice_ctx* ctx, int64_t want) {
+    if (want <= ctx->col_cap) return SDICE_OK;
+    if (ctx->d_col) {
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_col);
+    }
+    ctx->d_col = nullptr;
+    ctx->col_cap = 0;
+    hipError_t e = hipMalloc((void**)&ctx->d_col, (size_t)want * 4);
+    if (e != hipSuccess) {
+        sdice_set_error("sdice_cluster: hipMalloc of %lld neighbour indices failed: %s", (long long)want, hipGetErrorString(e));
+        return SDICE_ERR_NOMEM;
+    }
+    ctx->col_cap = want;
+    return SDICE_OK;
+}
+
+}  // namespace
+
+// Fetch the status block of the last fast-path run (synchronises).  Returns the flags.
+static int fast_fetch_status(sdice_ctx* ctx, unsigned long long* flags, int64_t* nnz, int64_t* reach) {
+    int64_t* hp = ctx->h_pinned;
+    SD_HIP(hipMemcpyAsync(hp, ctx->cluster_sb, (size_t)SB_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    *flags = (unsigned long long)hp[SB_FLAGS];
+    *nnz = hp[SB_NNZ];
+    int64_t rc = 0;
+    for (int i = 0; i < SB_SLOTS; ++i) rc = hp[SB_REACH + i] > rc ? hp[SB_REACH + i] : rc;
+    *reach = rc;
+    return SDICE_OK;
+}
+
+static int fast_flags_to_error(unsigned long long flags) {
+    if (flags & ST_INVALID) {
+        sdice_set_error("sdice_cluster: invalid junction (need 0 <= left <= right, chrom_rank >= 0, strand in {0,1})");
+        return SDICE_ERR_ARG;
+    }
+    if (flags & ST_DUP) {
+        sdice_set_error("sdice_cluster: duplicate junction (chrom, left, right, strand): the junctions must be distinct");
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+}
+
+// Resolve the status of an asynchronous sdice_cluster_dev (nnz == NULL).  Called by sdice_sync,
+// sdice_cluster_status and sdice_cluster_col_dev.
+int sd_cluster_resolve(sdice_ctx* ctx) {
+    if (!ctx->cluster_pending) return SDICE_OK;
+    ctx->cluster_pending = false;
+    unsigned long long flags = 0;
+    int64_t nnz = 0, reach = 0;
+    SD_TRY(fast_fetch_status(ctx, &flags, &nnz, &reach));
+    ctx->nnz = 0;
+    SD_TRY(fast_flags_to_error(flags));
+    if (flags & (ST_SLOT_OVERFLOW | ST_LOOKBACK)) {
+        sdice_set_error("sdice_cluster_dev (asynchronous): %s; call with nnz != NULL (synchronous) "
+                        "to take the generic path", (flags & ST_LOOKBACK) ? "the look-back gave up waiting" : "a sort bucket overflowed");
+        return SDICE_ERR_STATE;
+    }
+    if (flags & ST_COL_OVERFLOW) {
+        sdice_set_error("sdice_cluster_dev (asynchronous): %lld neighbour entries exceed the list capacity %lld; "
+                        "call once with nnz != NULL (synchronous) to size it", (long long)nnz, (long long)ctx->col_cap);
+        return SDICE_ERR_STATE;
+    }
+    ctx->nnz = nnz;
+    ctx->cluster_reach = (int)reach;
+    return SDICE_OK;
+}
+
+extern "C" int sdice_cluster_status(sdice_ctx* ctx, int64_t* nnz, int32_t* reach) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_TRY(sd_cluster_resolve(ctx));
+    if (nnz) *nnz = ctx->nnz;
+    if (reach) *reach = ctx->cluster_reach;
+    return SDICE_OK;
+}
+
+extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left,
+                                 const int32_t* d_right, const int8_t* d_strand, int32_t* d_row_of,
+                                 int64_t* d_row_ptr, int64_t* nnz_out) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
+    SD_HIP(hipSetDevice(ctx->device));
+    ctx->cluster_pending = false;
+    const bool legacy = n > FAST_MAX_N || ctx->param("cluster.generic", 0) || ctx->param("cluster.legacy", 0);
+    if (legacy || n == 0) return sd_cluster_legacy(ctx, n, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, nnz_out);
+    SD_ARG(d_chrom && d_left && d_right && d_strand && d_row_of && d_row_ptr, "NULL pointer");
+    ctx->nnz = 0;
+    ctx->cluster_reach = 0;
+    if (nnz_out) *nnz_out = 0;
+
+    FastPlan pl;
+    SD_TRY(fast_plan(ctx, n, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, pl));
+    FastArgs& a = pl.a;
+    // list capacity: what the last clustering needed, at least 16 entries per junction
+    SD_TRY(ensure_col(ctx, 16 * n + 1024));
+
+    SD_HIP(hipMemsetAsync(pl.zero_base, 0, pl.zero_bytes, ctx->stream));
+    if (a.S == 0) SD_HIP(hipMemsetAsync(a.sb, 0, (size_t)SB_WORDS * 8, ctx->stream));   // (else cleared by the rank kernel)
+    if (a.S > 0) {
+        const unsigned g = grid_for(a.S, 256);
+        SD_LAUNCH(ctx, "sample_rank_kernel", sample_rank_kernel, dim3(g, g), dim3(256), 0, a);
+        SD_LAUNCH(ctx, "splitter_kernel", splitter_kernel, dim3(g), dim3(256), 0, a);
+    }
+    {
+        const size_t lds = (size_t)a.B * 16;
+        // tiles of 2048 keys (512 threads) up to 1 M keys keep >= 2 workgroups per CU busy; 4096 beyond
+        if (n <= (1 << 21)) {
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter_kernel<512>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SD_LAUNCH(ctx, "bucket_scatter_kernel", (bucket_scatter_kernel<512>), dim3(grid_for(n, 512 * SC_KPT)), dim3(512), lds, a);
+        } else {
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter_kernel<1024>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SD_LAUNCH(ctx, "bucket_scatter_kernel", (bucket_scatter_kernel<1024>), dim3(grid_for(n, 1024 * SC_KPT)), dim3(1024), lds, a);
+        }
+    }
+    {
+        const size_t lds = SORT_LDS_BYTES;
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SD_LAUNCH(ctx, "bucket_sort_kernel", bucket_sort_kernel, dim3((unsigned)a.B), dim3(SORT_T), lds, a);
+    }
+    SD_TRY(launch_neighbours(ctx, pl));
+
+    if (!nnz_out) {          // asynchronous: the status is resolved at the next synchronising call
+        ctx->cluster_pending = true;
+        return SDICE_OK;
+    }
+    unsigned long long flags = 0;
+    int64_t nnz = 0, reach = 0;
+    SD_TRY(fast_fetch_status(ctx, &flags, &nnz, &reach));
+    SD_TRY(fast_flags_to_error(flags));
+    if (flags & (ST_SLOT_OVERFLOW | ST_LOOKBACK))      // (> 8x the mean bucket size between two splitters, or an unexpected dispatch order)
+        return sd_cluster_legacy(ctx, n, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, nnz_out);
+    if (flags & ST_COL_OVERFLOW) {
+        SD_TRY(ensure_col(ctx, nnz + nnz / 8 + 1024));
+        SD_HIP(hipMemsetAsync(pl.zero_base, 0, pl.k4_zero_bytes, ctx->stream));
+        // flags, ticket, total and reach start over; the maximum length (words SB_MAXLEN..) stays
+        SD_HIP(hipMemsetAsync(a.sb, 0, (size_t)SB_MAXLEN * 8, ctx->stream));
+        SD_HIP(hipMemsetAsync(a.sb + SB_REACH, 0, (size_t)SB_SLOTS * 8, ctx->stream));
+        SD_TRY(launch_neighbours(ctx, pl));
+        SD_TRY(fast_fetch_status(ctx, &flags, &nnz, &reach));
+        if (flags) {
+            sdice_set_error("sdice_cluster: neighbour pass failed after resizing (flags %llu)", flags);
+            return SDICE_ERR_STATE;
+        }
+    }
+    ctx->nnz = nnz;
+    ctx->cluster_reach = (int)reach;
+    *nnz_out = nnz;
+    return SDICE_OK;
+}

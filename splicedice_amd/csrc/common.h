@@ -71,6 +71,8 @@ struct sdice_ctx {
     int64_t nnz = 0;
     int cluster_reach = 0;   // max |row(neighbour) - row| of the last clustering (PS halo hint)
     int64_t* h_pinned = nullptr;  // small pinned buffer for scalar read-backs
+    void* cluster_sb = nullptr;   // device status block of the fast clustering path (persistent, 768 B)
+    bool cluster_pending = false; // an asynchronous sdice_cluster_dev has not been resolved yet
 
     // log-factorial table of the Fisher kernel: lf[k] = lgamma(k+1)
     double* d_lf = nullptr;
@@ -114,6 +116,9 @@ int sd_prof_drain(sdice_ctx* ctx);
     } while (0)
 
 static inline int64_t sd_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// status of an asynchronous sdice_cluster_dev (synchronises when one is pending)
+int sd_cluster_resolve(sdice_ctx* ctx);
 
 // ---- internal device-level primitives shared between translation units ----
 // stable LSD radix sort of (key64, val32) pairs; only the bits set in `bit_mask`

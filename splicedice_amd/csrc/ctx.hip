@@ -131,6 +131,7 @@ extern "C" int sdice_ctx_destroy(sdice_ctx* ctx) {
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->d_col) (void)hipFree(ctx->d_col);
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
+    if (ctx->cluster_sb) (void)hipFree(ctx->cluster_sb);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     ctx->arena.release();
     (void)hipStreamDestroy(ctx->stream);
@@ -141,7 +142,7 @@ extern "C" int sdice_ctx_destroy(sdice_ctx* ctx) {
 extern "C" int sdice_sync(sdice_ctx* ctx) {
     SD_ARG(ctx, "ctx is NULL");
     SD_HIP(hipStreamSynchronize(ctx->stream));
-    return SDICE_OK;
+    return sd_cluster_resolve(ctx);      // (reports the deferred status of an asynchronous clustering)
 }
 
 extern "C" int sdice_device_info(sdice_ctx* ctx, char* name, int name_cap, int* compute_units,
@@ -320,7 +321,7 @@ extern "C" int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms) {
 extern "C" int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value) {
     SD_ARG(ctx && name, "bad arguments");
     static const char* known[] = {"ps.lds_bytes", "ps.tile_rows", "ps.threads", "ps.chunk_cols",
-                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "ps.ablate", "ps.quantize3", "sort.bits", "sort.rounds", "ranksum.variant", "ranksum.ablate",
+                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "ps.ablate", "ps.quantize3", "sort.bits", "sort.rounds", "ranksum.variant", "ranksum.ablate",
                                   "fisher.threads", "fisher.table_max", nullptr};
     for (int i = 0; known[i]; ++i)
         if (strcmp(known[i], name) == 0) {

@@ -250,15 +250,24 @@ class Context:
         return scores, counts
 
     # ---------------------------------------------------------------- device entry points
-    def cluster_dev(self, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr):
-        """-> (DeviceArray col view (ctx-owned), nnz)"""
+    def cluster_dev(self, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, sync=True):
+        """-> (DeviceArray col view (ctx-owned), nnz).  sync=False enqueues the whole chain without a host
+        round trip (nnz is then None; `cluster_status()` / `sync()` report it and any deferred error)."""
         n = d_chrom.shape[0]
         nnz = C.c_int64()
         check(self.lib.sdice_cluster_dev(self.h, n, d_chrom.ptr, d_left.ptr, d_right.ptr, d_strand.ptr, d_row_of.ptr,
-                                         d_row_ptr.ptr, C.byref(nnz)), "sdice_cluster_dev")
+                                         d_row_ptr.ptr, C.byref(nnz) if sync else None), "sdice_cluster_dev")
         p = C.c_void_p()
         check(self.lib.sdice_cluster_col_dev(self.h, C.byref(p), None), "sdice_cluster_col_dev")
+        if not sync:
+            return DeviceArray(self, (0,), np.int32, ptr=p.value, owned=False), None
         return DeviceArray(self, (nnz.value,), np.int32, ptr=p.value, owned=False), nnz.value
+
+    def cluster_status(self):
+        """resolve an asynchronous cluster_dev -> (nnz, reach); raises on a deferred error"""
+        nnz, reach = C.c_int64(), C.c_int32()
+        check(self.lib.sdice_cluster_status(self.h, C.byref(nnz), C.byref(reach)), "sdice_cluster_status")
+        return nnz.value, reach.value
 
     def ps_dev(self, d_counts, d_row_ptr, d_col, d_excl, d_ps):
         n, s = d_counts.shape

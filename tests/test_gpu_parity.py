@@ -44,10 +44,11 @@ def test_cluster_vs_oracle(ctx, n, seed, kw):
         assert np.array_equal(g, w)
 
 
-@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("generic", [0, 1, 2])
 def test_cluster_paths_and_wide_keys(ctx, generic):
-    """packed single-sort path vs the generic two-sort path; coordinates near 2^31 and chrom
-    ranks up to 2^20 force wide fields (the packed path must refuse keys that do not fit)."""
+    """fast path (0) vs the radix paths of cluster.hip: generic two-sort (1) and packed single-sort (2);
+    coordinates near 2^31 and chrom ranks up to 2^20 force wide fields (the packed path must refuse
+    keys that do not fit)."""
     rng = np.random.default_rng(77)
     n = 4000
     cr = rng.choice(np.array([0, 1, 7, 1 << 20, (1 << 20) + 1], np.int32), size=n)
@@ -59,13 +60,15 @@ def test_cluster_paths_and_wide_keys(ctx, generic):
     rng.shuffle(key)
     cr, left, right, strand = key[:, 0].astype(np.int32), key[:, 1].astype(np.int32), key[:, 2].astype(np.int32), key[:, 3].astype(np.int8)
     want = O.cluster_csr(cr, left, right, strand)
-    ctx.set_param("cluster.generic", generic)
+    ctx.set_param("cluster.generic", int(generic == 1))
+    ctx.set_param("cluster.legacy", int(generic == 2))
     try:
         got = ctx.cluster(cr, left, right, strand)
         cr2, l2, r2, s2 = synth.make_junctions(9000, 31, n_chrom=7)
         got2 = ctx.cluster(cr2, l2, r2, s2)
     finally:
         ctx.set_param("cluster.generic", 0)
+        ctx.set_param("cluster.legacy", 0)
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     for g, w in zip(got2, O.cluster_csr(cr2, l2, r2, s2)):
@@ -82,6 +85,105 @@ def test_cluster_touching_and_nested(ctx):
     got = ctx.cluster(cr, left, right, strand)
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("n,seed,kw,lds_cap", [
+    (2049, 41, {}, 0),                                   # two buckets
+    (70000, 42, {}, 0),                                  # 35 buckets, many tiles of the neighbour kernel
+    (70000, 43, dict(n_chrom=1), 0),
+    (40000, 44, dict(n_chrom=900, gene_spacing=2500), 0),
+    (30000, 45, {}, 64),                                 # every bucket beyond the LDS capacity: in-place HBM sort
+    (3000, 46, dict(n_chrom=2, gene_spacing=40, len_span=150000), 0),   # degree ~ hundreds: list longer than 16 n
+    (300_000, 47, {}, 0),
+])
+def test_cluster_fast_path_buckets(ctx, n, seed, kw, lds_cap):
+    """sample sort + tiled neighbour lists of cluster_fast.hip across bucket / tile boundaries"""
+    cr, left, right, strand = synth.make_junctions(n, seed, **kw)
+    if n <= 70000:
+        want = O.cluster_csr(cr, left, right, strand)
+    else:                                                # the oracle's Python sweep is too slow here: radix path
+        ctx.set_param("cluster.legacy", 1)
+        try:
+            want = ctx.cluster(cr, left, right, strand)
+        finally:
+            ctx.set_param("cluster.legacy", 0)
+    ctx.set_param("cluster.lds_cap", lds_cap)
+    try:
+        got = ctx.cluster(cr, left, right, strand)
+    finally:
+        ctx.set_param("cluster.lds_cap", 0)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_cluster_sorted_and_reversed_input(ctx):
+    """input already in row order (what `quant` hands over after the junction union) and reversed"""
+    cr, left, right, strand = synth.make_junctions(50000, 48)
+    order = np.lexsort((strand, right, left, cr))
+    for o in (order, order[::-1]):
+        a = [np.ascontiguousarray(x[o]) for x in (cr, left, right, strand)]
+        want = O.cluster_csr(*a)
+        got = ctx.cluster(*a)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        assert np.array_equal(got[0], np.arange(50000) if o is order else np.arange(50000)[::-1])
+
+
+def test_cluster_async_and_deferred_errors(ctx):
+    from splicedice_amd.engine import SdiceError
+    n = 20000
+    cr, left, right, strand = synth.make_junctions(n, 49)
+    want = O.cluster_csr(cr, left, right, strand)
+    d = [ctx.to_device(x) for x in (cr, left, right, strand)]
+    d_row_of, d_row_ptr = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    d_col, nnz = ctx.cluster_dev(*d, d_row_of, d_row_ptr, sync=False)
+    assert nnz is None
+    nnz, reach = ctx.cluster_status()
+    assert nnz == want[2].size and reach > 0
+    assert np.array_equal(d_row_of.to_host(), want[0]) and np.array_equal(d_row_ptr.to_host(), want[1])
+    assert np.array_equal(d_col.offset(0, (nnz,)).to_host(), want[2])
+    rows = np.repeat(np.arange(n), np.diff(want[1]))
+    assert reach == int(np.abs(rows - want[2]).max())
+    # a duplicate junction: synchronous call raises, asynchronous call reports at the next sync and
+    # leaves an all-zero row_ptr behind
+    cr2, left2, right2, strand2 = cr.copy(), left.copy(), right.copy(), strand.copy()
+    cr2[7], left2[7], right2[7], strand2[7] = cr2[11], left2[11], right2[11], strand2[11]
+    with pytest.raises(SdiceError, match="duplicate"):
+        ctx.cluster(cr2, left2, right2, strand2)
+    d2 = [ctx.to_device(x) for x in (cr2, left2, right2, strand2)]
+    ctx.cluster_dev(*d2, d_row_of, d_row_ptr, sync=False)
+    with pytest.raises(SdiceError, match="duplicate"):
+        ctx.sync()
+    assert not d_row_ptr.to_host().any()
+    ctx.sync()                                          # the error was consumed
+    # invalid coordinates, asynchronous
+    left3 = left.copy()
+    left3[5] = right[5] + 1
+    ctx.cluster_dev(d[0], ctx.to_device(left3), d[2], d[3], d_row_of, d_row_ptr, sync=False)
+    with pytest.raises(SdiceError, match="invalid junction"):
+        ctx.cluster_status()
+    # a list longer than the buffer: asynchronous call says so, a synchronous one sizes the buffer
+    crd, ld, rd, sd = synth.make_junctions(3000, 50, n_chrom=1, gene_spacing=30, len_span=200000)
+    wantd = O.cluster_csr(crd, ld, rd, sd)
+    assert wantd[2].size > 16 * 3000 + 1024
+    dd = [ctx.to_device(x) for x in (crd, ld, rd, sd)]
+    d_row_of2, d_row_ptr2 = ctx.empty(3000, np.int32), ctx.empty(3001, np.int64)
+    fresh = type(ctx)(0)                                 # a context whose list buffer has never grown
+    try:
+        fd = [fresh.to_device(x) for x in (crd, ld, rd, sd)]
+        f_row_of, f_row_ptr = fresh.empty(3000, np.int32), fresh.empty(3001, np.int64)
+        fresh.cluster_dev(*fd, f_row_of, f_row_ptr, sync=False)
+        with pytest.raises(SdiceError, match="capacity"):
+            fresh.sync()
+        rp = f_row_ptr.to_host()
+        assert (np.diff(rp) >= 0).all() and rp[-1] <= 16 * 3000 + 1024      # clamped, in bounds
+        f_col, f_nnz = fresh.cluster_dev(*fd, f_row_of, f_row_ptr)           # synchronous: grows and re-runs
+        assert f_nnz == wantd[2].size and np.array_equal(f_col.to_host(), wantd[2])
+        assert np.array_equal(f_row_ptr.to_host(), wantd[1])
+        fresh.cluster_dev(*fd, f_row_of, f_row_ptr, sync=False)               # now it fits
+        assert fresh.cluster_status()[0] == wantd[2].size
+    finally:
+        fresh.close()
 
 
 def test_cluster_empty_and_invalid(ctx):

@@ -1,0 +1,68 @@
+// Machine-model probes (tuning aid, not product): dependent VALU chain, dependent LDS chain,
+// LDS streaming, barrier cost.  Prints ns per op for one wave per SIMD and for full occupancy.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+__global__ void k_valu(uint32_t* out, int iters) {
+    uint32_t x = threadIdx.x, y = blockIdx.x;
+    for (int i = 0; i < iters; ++i) { x = x * 3u + y; y = y ^ x; x += 7u; y += x >> 3; }
+    if (x == 0x12345678u) out[0] = y;
+}
+__global__ void k_valu64(uint64_t* out, int iters) {
+    uint64_t x = threadIdx.x, y = blockIdx.x + 5;
+    for (int i = 0; i < iters; ++i) { x = x > y ? x - y : y - x + 1; y += x >> 3; }
+    if (x == 0x12345678u) out[0] = y;
+}
+__global__ void k_lds_chain(uint32_t* out, int iters) {
+    __shared__ uint32_t s[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s[i] = (i * 97u + 13u) & 4095u;
+    __syncthreads();
+    uint32_t p = threadIdx.x;
+    for (int i = 0; i < iters; ++i) p = s[p];
+    if (p == 0xffffffffu) out[0] = p;
+}
+__global__ void k_lds_rw(uint64_t* out, int iters) {     // bitonic-like: 2 reads, compare, 2 writes per step
+    __shared__ uint64_t s[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s[i] = i * 0x9E3779B97F4A7C15ull;
+    __syncthreads();
+    const int t = threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        const int j = 1 << (i % 6);
+        const int off = t & (j - 1);
+        const int lo = (((t - off) << 1) + off) & 4095, hi = (lo + j) & 4095;
+        const uint64_t x = s[lo], y = s[hi];
+        s[lo] = y < x ? y : x; s[hi] = y < x ? x : y;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (s[t] == 1) out[0] = 1;
+}
+__global__ void k_barrier(uint32_t* out, int iters) {
+    __shared__ uint32_t s[1024];
+    s[threadIdx.x] = threadIdx.x;
+    for (int i = 0; i < iters; ++i) { __syncthreads(); s[threadIdx.x] += s[(threadIdx.x + 64) & 1023]; }
+    if (s[threadIdx.x] == 0xffffffffu) out[0] = 1;
+}
+
+template <typename F> float timeit(F f) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms;
+}
+int main() {
+    void* d; hipMalloc(&d, 1 << 20);
+    const int it = 1 << 14;
+    for (int rep = 0; rep < 2; ++rep) {
+        for (int wgs : {256, 2048}) for (int th : {256, 1024}) {
+            float a = timeit([&] { k_valu<<<wgs, th>>>((uint32_t*)d, it); });
+            float b = timeit([&] { k_valu64<<<wgs, th>>>((uint64_t*)d, it); });
+            float c = timeit([&] { k_lds_chain<<<wgs, th>>>((uint32_t*)d, it); });
+            float e = timeit([&] { k_lds_rw<<<wgs, th>>>((uint64_t*)d, it); });
+            float g = timeit([&] { k_barrier<<<wgs, 1024>>>((uint32_t*)d, it); });
+            printf("wgs %4d threads %4d : valu32 %.2f ns/iter(5 ops)  valu64 %.2f ns/iter  lds chain %.1f ns/hop  lds rw step %.1f ns  barrier+lds %.1f ns\n",
+                   wgs, th, a * 1e6 / it, b * 1e6 / it, c * 1e6 / it, e * 1e6 / it, g * 1e6 / it);
+        }
+    }
+    return 0;
+}
