@@ -50,8 +50,6 @@ struct PsArgs {
     int n_tiles;
     int tiles_per_xcd;  // 0 = no remap
     int n_chunks;       // column chunks per row tile
-    int ablate;         // timing experiments only: 1 skip gather, 2 skip staging loads, 4 skip stores
-    int quant3;         // param ps.quantize3: store the '.3f' text round trip of PS (K4 fused into the store)
 };
 
 template <int VEC> struct Vt;
@@ -83,6 +81,11 @@ template <> __device__ __forceinline__ void store_f<4>(float* p, const float (&o
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
 }
 template <> __device__ __forceinline__ void store_f<1>(float* p, const float (&o)[1]) { *p = o[0]; }
+__device__ __forceinline__ void store_f4_nt(float* p, const float (&o)[4]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f v = {o[0], o[1], o[2], o[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+}
 
 template <int VEC, typename ACC> __device__ __forceinline__ void store_excl(int64_t* p, const ACC (&acc)[VEC]) {
     if (VEC == 4) {
@@ -110,10 +113,26 @@ __device__ __forceinline__ float div_small_ints(float a, float t) {
     return __builtin_fmaf(rem, r, q);
 }
 
+// The same sequence on two quotients at once: v_pk_fma_f32 / v_pk_mul_f32 carry two float32 lanes
+// per instruction (the reciprocal seed has no packed form).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f div_small_ints2(v2f a, v2f t) {
+    v2f r;
+    r.x = __builtin_amdgcn_rcpf(t.x); r.y = __builtin_amdgcn_rcpf(t.y);
+    const v2f one = {1.0f, 1.0f};
+    const v2f e = __builtin_elementwise_fma(-t, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    v2f q = a * r;
+    v2f rem = __builtin_elementwise_fma(-t, q, a);
+    q = __builtin_elementwise_fma(rem, r, q);
+    rem = __builtin_elementwise_fma(-t, q, a);
+    return __builtin_elementwise_fma(rem, r, q);
+}
+
 // Fast item: every neighbour offset comes from the LDS stage and lies inside the staged window,
 // the tile's bound keeps incl + excl < 2^24 -> 32-bit sums, float32 quotient.  Returns false
 // (nothing stored) as soon as a neighbour is outside the window; the caller then runs ps_item_slow.
-template <int VEC, bool WEXCL, bool WPS, bool CHECK>
+template <int VEC, bool WEXCL, bool WPS, bool CHECK, bool Q3, int ABL>
 __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB, const int* colL, int k0, int k1,
                                              int cbytes, int own_off, int64_t out_index, int zero_off) {
     typedef typename Vt<VEC>::I VI;
@@ -148,15 +167,35 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
     const VI own = *reinterpret_cast<const VI*>(tileB + own_off + cbytes);
     if (WPS) {
         float o[VEC];
+        if (VEC == 4) {
+            // two packed quotients per instruction
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            const unsigned in = comp(own, q);
-            o[q] = div_small_ints((float)in, (float)(in + acc[q]));
-            // fused K4: k = rint(ps * 1000) (exact product in float64, half-even as the formatter),
-            // float32(k / 1000.0) == correctly rounded float32 quotient of the two small integers
-            if (a.quant3) o[q] = div_small_ints((float)rint((double)o[q] * 1000.0), 1000.0f);
+            for (int q = 0; q < VEC; q += 2) {
+                const unsigned i0 = comp(own, q), i1 = comp(own, q + 1);
+                const v2f num = {(float)i0, (float)i1};
+                const v2f den = {(float)(i0 + acc[q]), (float)(i1 + acc[q + 1])};
+                v2f ps2 = div_small_ints2(num, den);
+                if (Q3) {
+                    // fused K4: k = rint(ps * 1000) (exact product in float64, half-even as the formatter),
+                    // float32(k / 1000.0) == correctly rounded float32 quotient of the two small integers
+                    const v2f k2 = {(float)rint((double)ps2.x * 1000.0), (float)rint((double)ps2.y * 1000.0)};
+                    const v2f th = {1000.0f, 1000.0f};
+                    ps2 = div_small_ints2(k2, th);
+                }
+                o[q] = ps2.x; o[q + 1] = ps2.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const unsigned in = comp(own, q);
+                o[q] = div_small_ints((float)in, (float)(in + acc[q]));
+                if (Q3) o[q] = div_small_ints((float)rint((double)o[q] * 1000.0), 1000.0f);
+            }
         }
-        if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
+        // non-temporal store: the PS matrix is written once and not re-read by this kernel, keeping it
+        // out of the L2 leaves the halo rows of the count matrix there (-2.5 % at 1M x 100; ABL 8 = plain store)
+        if (VEC == 4 && !(ABL & 8)) { if (!(ABL & 4)) store_f4_nt(a.ps + out_index, reinterpret_cast<const float (&)[4]>(o)); }
+        else if (!(ABL & 4)) store_f<VEC>(a.ps + out_index, o);
     }
     if (WEXCL) store_excl<VEC, unsigned>(a.excl + out_index, acc);
     return true;
@@ -164,7 +203,7 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
 
 // General item: neighbours from the LDS window or from global memory, indices from the LDS stage
 // or from global memory, 64-bit sums, float64 division.  Exact for any valid CSR and any counts.
-template <int VEC, bool WEXCL, bool WPS>
+template <int VEC, bool WEXCL, bool WPS, bool Q3, int ABL>
 __device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB, const int* colL, bool col_in_lds,
                                              int64_t kbase, int k0, int k1, int slo, int wrows, int ldw, int c0, int cvec,
                                              int own_off, int64_t out_index) {
@@ -193,14 +232,17 @@ __device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB,
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             o[q] = ps_value64(comp(own, q), acc[q]);
-            if (a.quant3) o[q] = (float)(rint((double)o[q] * 1000.0) / 1000.0);
+            if (Q3) o[q] = (float)(rint((double)o[q] * 1000.0) / 1000.0);
         }
-        if (!(a.ablate & 4)) store_f<VEC>(a.ps + out_index, o);
+        if (!(ABL & 4)) store_f<VEC>(a.ps + out_index, o);
     }
     if (WEXCL) store_excl<VEC, unsigned long long>(a.excl + out_index, acc);
 }
 
-template <int VEC, bool WEXCL, bool WPS>
+// Q3: store the '.3f' text round trip of PS (K4 fused into the store, param ps.quantize3).
+// ABL: timing experiments only (param ps.ablate: 1 skip gather, 2 skip staging loads, 4 skip stores);
+//      the production instantiations have ABL = 0 and no trace of it.
+template <int VEC, bool WEXCL, bool WPS, bool Q3, int ABL>
 __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     typedef typename Vt<VEC>::I VI;
     extern __shared__ int4 smem4[];
@@ -254,7 +296,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
             const VI* g = reinterpret_cast<const VI*>(a.counts + (int64_t)slo * a.s);
             VI* l = reinterpret_cast<VI*>(tileL);
             int i = tid;
-            if (a.ablate & 2) i = total;
+            if (ABL & 2) i = total;
             for (; i + 3 * T < total; i += 4 * T) {
                 const VI v0 = g[i], v1 = g[i + T], v2 = g[i + 2 * T], v3 = g[i + 3 * T];
                 l[i] = v0; l[i + T] = v1; l[i + 2 * T] = v2; l[i + 3 * T] = v3;
@@ -264,7 +306,7 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
         } else {
             // row segments of cwc columns: 4 independent loads in flight per lane
             const int* gbase = a.counts + (int64_t)slo * a.s + c0;
-            for (int i = (a.ablate & 2) ? total : tid; i < total; i += 4 * T) {
+            for (int i = (ABL & 2) ? total : tid; i < total; i += 4 * T) {
                 VI v[4];
                 int lofs[4];
 #pragma unroll
@@ -323,15 +365,15 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
         const int dr = T / V, dc = T - dr * V;
         const int own_base = (int)(r0 - slo);
         for (int it = tid; it < items; it += T) {
-            const int k0 = rpL[ri], k1 = (a.ablate & 1) ? k0 : rpL[ri + 1];
+            const int k0 = rpL[ri], k1 = (ABL & 1) ? k0 : rpL[ri + 1];
             const int64_t o = (r0 + ri) * a.s + c0 + c * VEC;
             const int own_off = (own_base + ri) * ldw * 4;
             bool done = false;
             if (fast)
-                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
-                              : ps_item_fast<VEC, WEXCL, WPS, true>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
+                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, ABL>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
+                              : ps_item_fast<VEC, WEXCL, WPS, true, Q3, ABL>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
             if (!done)
-                ps_item_slow<VEC, WEXCL, WPS>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
+                ps_item_slow<VEC, WEXCL, WPS, Q3, ABL>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
                                               own_off, o);
             c += dc; ri += dr;
             if (c >= V) { c -= V; ri += 1; }
@@ -367,19 +409,33 @@ __global__ void mark_low_kernel(float* __restrict__ ps, const int64_t* __restric
     }
 }
 
-template <int VEC>
-int launch_ps(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps) {
-#define SD_PS_CASE(WE, WP)                                                                         \
-    do {                                                                                           \
-        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_kernel<VEC, WE, WP>),      \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-        SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_kernel<VEC, WE, WP>), grid, dim3(threads), lds, a); \
-    } while (0)
-    if (wexcl && wps) SD_PS_CASE(true, true);
-    else if (wexcl) SD_PS_CASE(true, false);
-    else SD_PS_CASE(false, true);
-#undef SD_PS_CASE
+template <int VEC, bool WE, bool WP, bool Q3, int ABL>
+int launch_ps_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_kernel<VEC, WE, WP, Q3, ABL>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_kernel<VEC, WE, WP, Q3, ABL>), grid, dim3(threads), lds, a);
     return SDICE_OK;
+}
+
+template <int VEC>
+int launch_ps(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps, bool q3, int abl) {
+    if (abl && VEC == 4 && !wexcl && wps && !q3) {        // timing experiments (one shape only)
+        if (abl & 8) return launch_ps_one<4, false, true, false, 8>(ctx, a, threads, lds, grid);
+        switch (abl & 7) {
+            case 1: return launch_ps_one<4, false, true, false, 1>(ctx, a, threads, lds, grid);
+            case 2: return launch_ps_one<4, false, true, false, 2>(ctx, a, threads, lds, grid);
+            case 3: return launch_ps_one<4, false, true, false, 3>(ctx, a, threads, lds, grid);
+            case 4: return launch_ps_one<4, false, true, false, 4>(ctx, a, threads, lds, grid);
+            case 5: return launch_ps_one<4, false, true, false, 5>(ctx, a, threads, lds, grid);
+            case 6: return launch_ps_one<4, false, true, false, 6>(ctx, a, threads, lds, grid);
+            default: return launch_ps_one<4, false, true, false, 7>(ctx, a, threads, lds, grid);
+        }
+    }
+    if (wexcl && wps) return q3 ? launch_ps_one<VEC, true, true, true, 0>(ctx, a, threads, lds, grid)
+                                : launch_ps_one<VEC, true, true, false, 0>(ctx, a, threads, lds, grid);
+    if (wexcl) return launch_ps_one<VEC, true, false, false, 0>(ctx, a, threads, lds, grid);
+    return q3 ? launch_ps_one<VEC, false, true, true, 0>(ctx, a, threads, lds, grid)
+              : launch_ps_one<VEC, false, true, false, 0>(ctx, a, threads, lds, grid);
 }
 
 }  // namespace
@@ -455,8 +511,8 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     a.n_chunks = n_chunks;
     int gx = a.n_tiles;
     a.tiles_per_xcd = 0;
-    a.ablate = (int)ctx->param("ps.ablate", 0);
-    a.quant3 = (int)ctx->param("ps.quantize3", 0);
+    const int abl = (int)ctx->param("ps.ablate", 0);
+    const bool q3 = ctx->param("ps.quantize3", 0) != 0;
     if (ctx->param("ps.xcd_remap", 1) && a.n_tiles >= 64) {
         a.tiles_per_xcd = (int)sd_ceil_div(a.n_tiles, 8);
         gx = a.tiles_per_xcd * 8;
@@ -464,8 +520,8 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     const size_t lds_bytes = (size_t)lds;
     SD_ARG((int64_t)gx * n_chunks < (int64_t)1 << 31, "grid too large");
     dim3 grid((unsigned)((int64_t)gx * n_chunks));
-    if (vec == 4) return launch_ps<4>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr);
-    return launch_ps<1>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr);
+    if (vec == 4) return launch_ps<4>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
+    return launch_ps<1>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
 }
 
 extern "C" int sdice_ps(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* counts,
