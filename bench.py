@@ -28,6 +28,11 @@ max-over-ranks time.  "roofline" is for the dominant kernel, timed with HIP even
 library's stream inside the timed region (profiling mode 2 records only that kernel).
 "cpu_baseline" times the oracle's loop-for-loop restatement of the reference on a bounded
 sample, on rank 0 at N=1 only; it is a reported baseline, never the thing measured above.
+
+At N=1 the line also carries "also": the same measurement (value, roofline, cpu_baseline, verify) for
+the north-star size (quant 2M x 500) and for BASELINE configs 3, 4 (one GPU's shard) and 5 (one GPU's
+shard), a few steps each (--no-also skips them).  Their big tables are one seeded host block repeated
+down the device matrix, so that generation stays bounded; the headline workload is generated whole.
 """
 import argparse
 import json
@@ -63,6 +68,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="junctions in the CPU-baseline sample")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under 'also'")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: ONE dataset of --junctions rows cut by shard_plan (strong scaling) instead of one shard per rank")
     return ap.parse_args()
 
 
@@ -106,6 +114,17 @@ class Dist:
             self.pg.destroy_process_group()
 
 
+def device_tiled(ctx, make_block, n, s, dtype, block_rows):
+    """[n, s] device matrix = one seeded host block of `block_rows` rows repeated down the rows
+    (bounded generation time for the multi-GB tables); -> (DeviceArray, host block)"""
+    blk = np.ascontiguousarray(make_block(min(n, block_rows)), dtype=dtype)
+    d = ctx.empty((n, s), dtype)
+    for a in range(0, n, blk.shape[0]):
+        b = min(n, a + blk.shape[0])
+        d.offset(a * s, (b - a, s)).upload(blk[: b - a])
+    return d, blk
+
+
 # ------------------------------------------------------------------------------------ workloads
 class QuantWorkload:
     name = "quant: cluster + PS"
@@ -114,17 +133,19 @@ class QuantWorkload:
     dtype = "int32 counts -> f32 PS"
     kernel = "ps_tile_kernel"
 
-    def __init__(self, ctx, rank, n, s):
+    def __init__(self, ctx, rank, n, s, block_rows=0):
         self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
         n, s = self.n, self.s
         t = time.time()
         self.junc = synth.make_junctions(n, 2 + 1000 * rank)          # this rank's chromosome group
         self.counts_host_seed = 20 + 1000 * rank
-        counts = synth.make_counts(n, s, self.counts_host_seed)       # rows already in output order
-        self.gen_s = time.time() - t
         self.d_j = [ctx.to_device(x) for x in self.junc]
         self.d_row_of, self.d_row_ptr = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
-        self.d_counts = ctx.to_device(counts)
+        # rows already in output order; block_rows > 0: one seeded block repeated (see device_tiled)
+        self.d_counts, counts = device_tiled(ctx, lambda m: synth.make_counts(m, s, self.counts_host_seed), n, s, np.int32,
+                                             block_rows or n)
+        self.tiled = counts.shape[0] < n
+        self.gen_s = time.time() - t
         self.sample_counts = counts[: min(n, 200_000)].copy()
         del counts
         self.d_ps = ctx.empty((n, s), np.float32)
@@ -146,7 +167,9 @@ class QuantWorkload:
         tag = "BASELINE config 2" if (self.n, self.s) == (1_000_000, 100) else \
             "north_star target size" if (self.n, self.s) == (2_000_000, 500) else "custom size"
         return {"workload": f"quant {self.n} junctions x {self.s} samples per GPU ({tag}), cluster+PS",
-                "junctions_per_gpu": self.n, "samples": self.s, "avg_overlap_degree": round(self.nnz / self.n, 2)}
+                "junctions_per_gpu": self.n, "samples": self.s, "avg_overlap_degree": round(self.nnz / self.n, 2),
+                "counts": f"one seeded block of {self.sample_counts.shape[0] if self.tiled else self.n} rows"
+                          + (" repeated down the matrix" if self.tiled else "")}
 
     def verify(self):
         """PS of the first rows against the oracle (same CSR prefix, vectorised restatement)."""
@@ -163,7 +186,7 @@ class QuantWorkload:
     def cpu_baseline(self, sample):
         """Loop-for-loop restatement (oracle) of getClusters + calculatePsi on `sample` junctions, 1 core."""
         from oracle import oracle_np as O
-        m = min(self.n, sample or 1_000_000)        # ~11 s of single-core work at the default size
+        m = min(self.n, sample or max(20_000, 100_000_000 // self.s))     # ~1e8 entries: ~11 s of single-core work
         # a junction set of its own with the same gene layout (a prefix of the shuffled 1M set
         # would be 25x sparser and have almost no overlaps)
         cr, l, r, st = synth.make_junctions(m, 7)
@@ -184,16 +207,16 @@ class CompareWorkload:
     dtype = "f32 PS -> f64 p"
     kernel = "ranksum_pair_kernel"
 
-    def __init__(self, ctx, rank, n, s):
+    def __init__(self, ctx, rank, n, s, block_rows=0):
         self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
         n, s = self.n, self.s
         t = time.time()
-        ps = synth.make_ps_matrix(n, s, 3 + 1000 * rank)
+        self.d_ps, ps = device_tiled(ctx, lambda m: synth.make_ps_matrix(m, s, 3 + 1000 * rank), n, s, np.float32,
+                                     block_rows or n)
         self.gen_s = time.time() - t
         self.g1 = np.arange(0, s // 2, dtype=np.int32)
         self.g2 = np.arange(s // 2, s, dtype=np.int32)
         self.sample_ps = ps[: min(n, 100_000)].copy()
-        self.d_ps = ctx.to_device(ps)
         del ps
         self.d_g1, self.d_g2 = ctx.to_device(self.g1), ctx.to_device(self.g2)
         self.out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
@@ -243,7 +266,7 @@ class PairwiseWorkload:
     dtype = "int64 tables -> f64 p"
     kernel = "fisher_pairs_kernel"
 
-    def __init__(self, ctx, rank, n, s):
+    def __init__(self, ctx, rank, n, s, block_rows=0):
         # config 4 is 200k junctions x 200 samples sharded over 8 GPUs -> 25k junctions per GPU
         self.ctx, self.n, self.s = ctx, n or 25_000, s or 200
         n, s = self.n, self.s
@@ -313,9 +336,9 @@ class E2EWorkload(QuantWorkload):
     kernel = "ranksum_count_kernel"
     needs_comm = True
 
-    def __init__(self, ctx, rank, n, s):
+    def __init__(self, ctx, rank, n, s, block_rows=0):
         # config 5 is 5M junctions x 1000 samples over 8 GPUs -> 625k junctions per GPU
-        super().__init__(ctx, rank, n or 625_000, s or 1000)
+        super().__init__(ctx, rank, n or 625_000, s or 1000, block_rows)
         n, s = self.n, self.s
         self.g1 = np.arange(0, s // 2, dtype=np.int32)
         self.g2 = np.arange(s // 2, s, dtype=np.int32)
@@ -404,13 +427,14 @@ WORKLOADS = {"quant": QuantWorkload, "compare": CompareWorkload, "pairwise": Pai
 
 
 def traffic_from_profiles(workload, n, s):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes."""
+    """(HBM bytes per launch of the dominant kernel, provenance) from the committed rocprofv3 PMC passes:
+    the counters are collected in runs of their own (profiles/), not while this line is measured."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             for rec in json.load(fh):
                 if rec["workload"] == workload and rec["n"] == n and rec["s"] == s:
-                    return rec["hbm_bytes_per_launch"]
+                    return rec["hbm_bytes_per_launch"], "committed PMC pass: " + rec.get("source", path)
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -455,6 +479,48 @@ def reference_over_port(workload):
         return None
 
 
+def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
+    """warmup + timed steps of one workload -> (elapsed s [max over ranks], roofline dict, verify dict)"""
+    for _ in range(warmup):
+        wl.step()
+    ctx.sync()
+    ctx.prof_enable(2)
+    ctx.prof_reset()
+    dist.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    ctx.sync()                                   # (also resolves the deferred status of asynchronous clusterings)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.prof_query(wl.kernel)
+    ctx.prof_enable(0)
+    elapsed = dist.max(elapsed)
+    avg_ms = kernel_ms / launches if launches else float("nan")
+    achieved = wl.alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
+    traffic = traffic_from_profiles(wl.key, wl.n, wl.s)
+    roofline = {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": wl.alg_bytes,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": traffic[1] if traffic else "no PMC pass committed for this shape"}
+    v = None
+    if verify:
+        ok, checked = wl.verify()
+        v = {"ok": ok, "checked": checked}
+    return elapsed, roofline, v
+
+
+# what "also" reports at N=1: (key, workload class, n, s, rows of the repeated host block, steps, CPU sample)
+ALSO = [
+    ("quant_2m500", "quant", 2_000_000, 500, 200_000, 5, 100_000),         # the north-star size
+    ("compare_c3", "compare", 1_000_000, 100, 200_000, 10, 30_000),        # BASELINE config 3
+    ("pairwise_c4_shard", "pairwise", 25_000, 200, 0, 2, 10),              # config 4, one GPU's shard of 8
+    ("e2e_c5_shard", "e2e", 625_000, 1000, 125_000, 3, 12_000),            # config 5, one GPU's shard of 8
+]
+
+
 def main():
     args = parse_args()
     all_cores = None
@@ -471,30 +537,12 @@ def main():
     forced = os.environ.get("SDICE_BENCH_DEVICE")
     ctx = Context(int(forced) if forced is not None else (dist.local_rank if args.gpus > 1 else 0))
     wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
+    wl.key = args.workload
     if args.gpus > 1 and getattr(wl, "needs_comm", False):
         wl.setup_comm(dist, args.gpus)          # this workload has a real exchange step inside every step
 
-    for _ in range(args.warmup):
-        wl.step()
-    ctx.sync()
-    ctx.prof_enable(2)
-    ctx.prof_reset()
-    dist.barrier()
-    ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    ctx.sync()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    launches, kernel_ms = ctx.prof_query(wl.kernel)
-    ctx.prof_enable(0)
-    elapsed = dist.max(elapsed)
-
-    verify = None
-    if not args.no_verify:
-        ok, checked = wl.verify()
-        verify = {"ok": ok, "checked": checked}
+    elapsed, roofline, verify = measure(ctx, wl, dist, args.steps, args.warmup, args.gpus, not args.no_verify)
+    failed = bool(verify and not verify["ok"])
 
     allgather = None
     if args.gpus > 1 and not getattr(wl, "needs_comm", False):
@@ -513,7 +561,7 @@ def main():
             ms = ctx.timer_stop() / 5
             got = recv.to_host().reshape(args.gpus, wl.n)[:, 0]
             allgather = {"ok": bool(np.array_equal(got, np.arange(args.gpus))), "bytes_per_rank": wl.n * 8,
-                         "ms": round(ms, 4)}
+                         "ms": round(ms, 4), "rccl_ranks": args.gpus}
         except Exception as e:  # reported, never hidden: the timed steps above contain no collective
             allgather = {"ok": False, "error": str(e)[:300]}
         dist.barrier()
@@ -524,10 +572,9 @@ def main():
         cpu["all_cores"] = all_cores
         cpu["real_reference_over_port"] = reference_over_port(args.workload)
 
+    line = None
     if dist.rank == 0:
         total_units = wl.units * args.gpus * args.steps
-        avg_ms = kernel_ms / launches if launches else float("nan")
-        achieved = wl.alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
         info = ctx.device_info()
         line = {
             "metric": wl.metric, "value": total_units / elapsed, "unit": wl.unit, "n_gpus": args.gpus,
@@ -535,17 +582,41 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
             "data": "synthetic (seeded numpy PCG64; SURVEY.md 8(d))",
             "config": dict(wl.describe(), parallelism=f"junction shards x{args.gpus}, one rank per GPU"),
-            "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS, "avg_kernel_ms": avg_ms,
-                         "launches": launches, "algorithmic_bytes_per_launch": wl.alg_bytes,
-                         "traffic": traffic_from_profiles(args.workload, wl.n, wl.s)},
-            "cpu_baseline": cpu, "verify": verify, "allgather": allgather,
+            "roofline": roofline, "cpu_baseline": cpu, "verify": verify, "allgather": allgather,
             "device": info["name"].strip(), "gen_seconds": round(wl.gen_s, 1),
         }
+
+    # ---- the other configurations, same measurement, a few steps each (1 GPU only: the driver's N=1 line)
+    if args.gpus == 1 and not args.no_also and args.workload == "quant" and not args.n and not args.s:
+        del wl
+        also = {}
+        for key, kind, n, s, block, steps, cpu_sample in ALSO:
+            t_start = time.time()
+            try:
+                w = WORKLOADS[kind](ctx, 0, n, s, block)
+                w.key = kind
+                el, rl, vf = measure(ctx, w, dist, steps, 2, 1, not args.no_verify)
+                rec = {"metric": w.metric, "value": w.units * steps / el, "unit": w.unit, "steps": steps, "warmup": 2,
+                       "ms_per_step": el / steps * 1e3, "dtype": w.dtype, "config": w.describe(), "roofline": rl,
+                       "verify": vf, "gen_seconds": round(w.gen_s, 1)}
+                if not args.no_cpu_baseline:
+                    rec["cpu_baseline"] = w.cpu_baseline(cpu_sample)
+                    rec["cpu_baseline"]["real_reference_over_port"] = reference_over_port(kind)
+                failed = failed or bool(vf and not vf["ok"])
+                del w
+            except Exception as e:      # an extra record must not take the headline down; it is reported as failed
+                rec = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                failed = True
+            rec["wall_seconds"] = round(time.time() - t_start, 1)
+            also[key] = rec
+        line["also"] = also
+
+    if dist.rank == 0:
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     dist.close()
     ctx.close()
+    if failed:
+        sys.exit(3)              # a wrong result must not look like a successful benchmark
 
 
 if __name__ == "__main__":
