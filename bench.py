@@ -17,11 +17,13 @@ Workloads (BASELINE.json configs):
   e2e     (config 5 per-GPU shard)  : 625k junctions x 1000 samples; step = cluster + PS + quantise
           + rank-sum (500 v 500) + [RCCL all-gather of p-values at N>1] + BH; metric = PS entries/s.
 
-Multi-GPU: the junction axis is sharded, every rank owns the junctions of its own chromosome
-group (zero halo, no data-path collective inside a step -> weak scaling).  torch.distributed
-(gloo) is used only as the control plane (barrier, max-over-ranks); the data-plane collective
-is the library's own RCCL all-gather, exercised after the timed region and reported in
-"allgather" (it reassembles the per-junction result tables, not the PS matrix -- DESIGN.md).
+Multi-GPU (quant): ONE dataset -- the N = 1 junction set -- is cut into N row ranges at chromosome
+boundaries (zero halo) and every rank clusters + quantifies its own range: total work fixed, "scaling":
+"strong".  No data-path collective is needed inside a step; the all-gather of the PS shards that the
+north star names is timed after the loop and reported in "ps_allgather" beside the design that leaves
+the shards in their owners' HBM.  --weak gives every rank an independently generated shard instead
+(per-GPU work fixed).  torch.distributed (gloo) is the control plane only (barrier, max / sum over
+ranks, the 128-byte RCCL id); the collectives are the library's own RCCL calls.
 
 The timed region is bracketed by barrier + device sync on both sides; rank 0 prints the
 max-over-ranks time.  "roofline" is for the dominant kernel, timed with HIP events on the
@@ -69,8 +71,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="junctions in the CPU-baseline sample")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under 'also'")
-    ap.add_argument("--strong", action="store_true",
-                    help="N>1: ONE dataset of --junctions rows cut by shard_plan (strong scaling) instead of one shard per rank")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1, quant: one independently generated shard per rank (per-GPU work fixed) instead of the "
+                         "default: ONE dataset cut into N row ranges (total work fixed)")
     return ap.parse_args()
 
 
@@ -92,6 +95,14 @@ class Dist:
     def barrier(self):
         if self.pg:
             self.pg.barrier()
+
+    def sum(self, x):
+        if not self.pg:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.SUM)
+        return float(t[0])
 
     def max(self, x):
         if not self.pg:
@@ -198,6 +209,67 @@ class QuantWorkload:
         return {"value": m * self.s / dt, "unit": self.unit, "cores": 1, "kind": "port",
                 "sample": f"{m} junctions (same gene layout, avg degree ~7) x {self.s} samples: oracle get_clusters + calculate_psi "
                           f"(Python loops + numpy as the reference), {dt:.1f} s"}
+
+
+class StrongQuantWorkload(QuantWorkload):
+    """N > 1 (default): ONE dataset -- the N = 1 junction set -- cut into N row ranges at chromosome
+    boundaries (contiguous chromosome ranges with near-equal junction counts; rows are in (chrom, ...)
+    order, so no overlap edge crosses a cut: zero halo).  Every rank clusters and quantifies its own
+    range; the total work is fixed as N grows (strong scaling)."""
+    name = "quant: cluster + PS, one dataset sharded over the ranks"
+
+    def __init__(self, ctx, rank, world, n, s):
+        self.ctx, self.s = ctx, s or 100
+        self.n_total = n or 1_000_000
+        s = self.s
+        t = time.time()
+        cr, l, r, st = synth.make_junctions(self.n_total, 2)          # the N = 1 dataset, identical on every rank
+        self.ranges = synth.chrom_ranges(cr, world)
+        c_lo, c_hi, self.row_lo, self.row_hi = self.ranges[rank]
+        mine = (cr >= c_lo) & (cr < c_hi)
+        self.junc = tuple(np.ascontiguousarray(x[mine]) for x in (cr, l, r, st))
+        self.n = n_own = int(mine.sum())
+        assert n_own == self.row_hi - self.row_lo
+        counts = synth.make_counts_rows(self.row_lo, self.row_hi, s, 20)     # rows of the shared table, output order
+        self.gen_s = time.time() - t
+        self.tiled = False
+        self.d_j = [ctx.to_device(x) for x in self.junc]
+        self.d_row_of, self.d_row_ptr = ctx.empty(max(n_own, 1), np.int32), ctx.empty(n_own + 1, np.int64)
+        self.d_counts = ctx.to_device(counts if n_own else np.zeros((1, s), np.int32))
+        self.sample_counts = counts[: min(n_own, 200_000)].copy()
+        del counts
+        self.d_ps = ctx.empty((max(n_own, 1), s), np.float32)
+        self.nnz = 0
+        self.units = n_own * s
+        self.alg_bytes = 8.0 * n_own * s
+        self.world = world
+
+    def describe(self):
+        d = super().describe()
+        d["workload"] = (f"quant {self.n_total} junctions x {self.s} samples in total (BASELINE config 2 dataset), cut at "
+                         f"chromosome boundaries into {self.world} row ranges, cluster+PS on each")
+        d["junctions_total"] = self.n_total
+        d["rows_per_rank"] = [b[3] - b[2] for b in self.ranges]
+        return d
+
+    def ps_allgather(self, dist, reps=3):
+        """the collective BASELINE.json's north_star names -- all-gather of the PS shards over xGMI --
+        timed beside the design that leaves every shard in its owner's HBM"""
+        from splicedice_amd import distributed
+        comm = distributed.RcclComm(self.ctx, dist.rank, self.world, dist.bcast_bytes)
+        max_rows = max(b[3] - b[2] for b in self.ranges)
+        out = distributed.gather_ps_dev(self.ctx, comm, self.d_ps, self.n, self.s, max_rows)
+        self.ctx.sync()
+        dist.barrier()
+        self.ctx.timer_start()
+        for _ in range(reps):
+            out = distributed.gather_ps_dev(self.ctx, comm, self.d_ps, self.n, self.s, max_rows)
+        ms = self.ctx.timer_stop() / reps
+        got = out.offset(dist.rank * max_rows * self.s, (min(self.n, 64), self.s)).to_host()
+        ok = bool(np.array_equal(got, self.d_ps.offset(0, (min(self.n, 64), self.s)).to_host(), equal_nan=True))
+        total = self.world * max_rows * self.s * 4
+        return {"ok": ok, "ms": round(dist.max(ms), 4), "bytes_gathered_per_rank": total, "rccl_ranks": self.world,
+                "GB_per_s_per_rank": round(total * (self.world - 1) / self.world / (ms * 1e-3) / 1e9, 1)}
 
 
 class CompareWorkload:
@@ -536,7 +608,11 @@ def main():
     # flow on a one-GPU box -- RCCL then refuses the duplicate GPU and "allgather" reports it)
     forced = os.environ.get("SDICE_BENCH_DEVICE")
     ctx = Context(int(forced) if forced is not None else (dist.local_rank if args.gpus > 1 else 0))
-    wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
+    strong = args.gpus > 1 and args.workload == "quant" and not args.weak
+    if strong:
+        wl = StrongQuantWorkload(ctx, dist.rank, args.gpus, args.n, args.s)
+    else:
+        wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
     wl.key = args.workload
     if args.gpus > 1 and getattr(wl, "needs_comm", False):
         wl.setup_comm(dist, args.gpus)          # this workload has a real exchange step inside every step
@@ -544,8 +620,16 @@ def main():
     elapsed, roofline, verify = measure(ctx, wl, dist, args.steps, args.warmup, args.gpus, not args.no_verify)
     failed = bool(verify and not verify["ok"])
 
+    ps_allgather = None
+    if strong:
+        try:
+            ps_allgather = wl.ps_allgather(dist)
+        except Exception as e:      # reported, never hidden: the timed steps above contain no collective
+            ps_allgather = {"ok": False, "error": str(e)[:300]}
+        dist.barrier()
+
     allgather = None
-    if args.gpus > 1 and not getattr(wl, "needs_comm", False):
+    if args.gpus > 1 and not strong and not getattr(wl, "needs_comm", False):
         # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction)
         try:
             uid = ctx.comm_unique_id() if dist.rank == 0 else None
@@ -572,17 +656,20 @@ def main():
         cpu["all_cores"] = all_cores
         cpu["real_reference_over_port"] = reference_over_port(args.workload)
 
+    total_units = dist.sum(wl.units) * args.steps          # units all ranks processed
     line = None
     if dist.rank == 0:
-        total_units = wl.units * args.gpus * args.steps
         info = ctx.device_info()
         line = {
             "metric": wl.metric, "value": total_units / elapsed, "unit": wl.unit, "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": wl.dtype,
             "data": "synthetic (seeded numpy PCG64; SURVEY.md 8(d))",
             "config": dict(wl.describe(), parallelism=f"junction shards x{args.gpus}, one rank per GPU"),
             "roofline": roofline, "cpu_baseline": cpu, "verify": verify, "allgather": allgather,
+            "ps_allgather": ps_allgather,
+            "rccl_ranks": args.gpus if any(c and c.get("ok") for c in (ps_allgather, allgather)) or
+            (args.gpus > 1 and getattr(wl, "d_p_all", None) is not None) else (0 if args.gpus > 1 else None),
             "device": info["name"].strip(), "gen_seconds": round(wl.gen_s, 1),
         }
 

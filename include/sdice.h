@@ -160,6 +160,11 @@ int sdice_chi2_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* d_
  *      (compareSampleSets.py:235; pairwise_fisher.py:185,190). */
 int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q);
 int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double* d_q);
+/* BH over the PRESENT entries of a padded vector: entry i is present when tested[i] != 0 (tested == NULL:
+ * when p[i] >= 0); absent entries are left out of the ranking and of m and get q = 0.  The sharded
+ * compare gathers the per-junction table of every rank (padded to equal length) and corrects it in
+ * place on the device -- the reference compacts the tested rows first (compareSampleSets.py:223-235). */
+int sdice_bh_masked_dev(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, double* d_q);
 /* BH down each of `cols` columns of a row-major [n, cols] table, in place
  * (pairwise_fisher.py:187-191) */
 int sdice_bh_columns(sdice_ctx* ctx, int64_t n, int64_t cols, double* p_inout);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sdice_chi2_pairs_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp],
     "sdice_bh": [ctxp, C.c_int64, vp, vp],
     "sdice_bh_dev": [ctxp, C.c_int64, vp, vp],
+    "sdice_bh_masked_dev": [ctxp, C.c_int64, vp, vp, vp],
     "sdice_bh_columns": [ctxp, C.c_int64, C.c_int64, vp],
     "sdice_bh_columns_dev": [ctxp, C.c_int64, C.c_int64, vp],
     "sdice_write_table": [C.c_char_p, C.c_char_p, C.c_int64, C.c_int32, vp, vp, vp, C.c_int, C.c_int, C.c_int],

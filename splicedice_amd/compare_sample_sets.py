@@ -83,6 +83,26 @@ def compare(matrix, g1_idx, g2_idx, ctx):
     return keep, out
 
 
+def compare_sharded(matrix, g1_idx, g2_idx, ctx, L):
+    """compare() with the table rows cut into one block per rank (rows are independent here): every rank
+    tests its block, the per-row statistics are all-gathered (padded to equal length), rank 0 corrects."""
+    n = matrix.shape[0]
+    lo, hi = L.row_block(n)
+    maxk = max(max(L.row_block(n, r)[1] - L.row_block(n, r)[0] for r in range(L.world)), 1)
+    res = ctx.ranksum(np.ascontiguousarray(matrix[lo:hi]), g1_idx, g2_idx)
+    comm = L.comm(ctx)
+    full = {}
+    for k in ("tested", "p", "med1", "med2", "mean1", "mean2", "delta"):
+        pad = np.zeros(maxk, dtype=res[k].dtype)
+        pad[: hi - lo] = res[k]
+        g = comm.allgather(pad)
+        full[k] = np.concatenate([g[r * maxk: r * maxk + L.row_block(n, r)[1] - L.row_block(n, r)[0]] for r in range(L.world)])
+    keep = np.flatnonzero(full["tested"])
+    out = {k: full[k][keep] for k in ("p", "med1", "med2", "mean1", "mean2", "delta")}
+    out["corrected"] = ctx.bh(out["p"]) if (keep.size and L.root) else np.zeros(keep.size)
+    return keep, out
+
+
 def add_parser(parser):
     parser.add_argument("--psiSPLICEDICE", type=str, required=True,
                         help="Compressed NPZ formatted PSI matrix from 'splicedice quant'.")
@@ -97,6 +117,8 @@ def add_parser(parser):
 
 
 def run_with(args, ctx=None):
+    from . import mgpu
+    L = mgpu.launcher()             # (reads the torchrun environment before any GPU call)
     g1 = samples_from_manifest(args.manifest1)
     g2 = samples_from_manifest(args.manifest2)
     if len(g1) < 3 or len(g2) < 3:
@@ -108,12 +130,14 @@ def run_with(args, ctx=None):
     g2_idx = column_indices(g2, cols)
 
     own_ctx = ctx is None
-    ctx = ctx if ctx is not None else Context(0)
+    ctx = ctx if ctx is not None else Context(L.local_rank)
     try:
-        keep, r = compare(matrix, g1_idx, g2_idx, ctx)
+        keep, r = compare_sharded(matrix, g1_idx, g2_idx, ctx, L) if L.world > 1 else compare(matrix, g1_idx, g2_idx, ctx)
     finally:
         if own_ctx:
             ctx.close()
+    if not L.root:
+        return                       # one set of output files: rank 0 writes the table
 
     base_header = "event\tmean1\tmean2\tmedian1\tmedian2\tdelta\tp-value\tcorrected"
     if not args.annotation:

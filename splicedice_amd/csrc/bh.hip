@@ -30,6 +30,55 @@ __global__ void __launch_bounds__(256) bh_keys_kernel(const double* __restrict__
     idx[i] = (uint32_t)(i % m);          // position inside its segment
 }
 
+// Masked variant (one segment): entries with tested == 0 (or, without a mask, with p < 0) are absent --
+// they sort behind every p-value (all-ones key) and are counted out of m.  Used for the gathered,
+// padded per-junction table of a sharded compare (BH ranks the TESTED junctions only,
+// compareSampleSets.py:223-235) without compacting it on the host.
+__global__ void __launch_bounds__(256) bh_keys_masked_kernel(const double* __restrict__ p,
+                                                             const uint8_t* __restrict__ tested, int64_t n,
+                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                             unsigned long long* __restrict__ m_eff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool present = false;
+    if (i < n) {
+        double v = p[i];
+        present = tested ? tested[i] != 0 : !(v < 0.0);
+        if (v == 0.0) v = 0.0;
+        keys[i] = present ? (uint64_t)__double_as_longlong(v) : ~0ull;
+        idx[i] = (uint32_t)i;
+    }
+    const unsigned long long b = __ballot(present);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(m_eff, (unsigned long long)__popcll(b));
+}
+
+__global__ void __launch_bounds__(256) bh_raw_masked_kernel(const uint64_t* __restrict__ sorted, int64_t n,
+                                                            const unsigned long long* __restrict__ m_eff,
+                                                            uint64_t* __restrict__ raw_rev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t m = (int64_t)*m_eff;
+    uint64_t out = 0x7ff0000000000000ull;                 // +inf: absent entries never lower the running minimum
+    if (i < m) {
+        const double ps = __longlong_as_double((long long)sorted[i]);
+        out = (uint64_t)__double_as_longlong(ps / ((double)(i + 1) / (double)m));
+    }
+    raw_rev[n - 1 - i] = out;
+}
+
+__global__ void __launch_bounds__(256) bh_scatter_masked_kernel(const uint64_t* __restrict__ cummin_rev,
+                                                                const uint32_t* __restrict__ idx, int64_t n,
+                                                                const unsigned long long* __restrict__ m_eff,
+                                                                double* __restrict__ q) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = 0.0;                                        // absent entries get 0 (as the host code leaves them)
+    if (i < (int64_t)*m_eff) {
+        v = __longlong_as_double((long long)cummin_rev[n - 1 - i]);
+        if (v > 1.0) v = 1.0;
+    }
+    q[idx[i]] = v;
+}
+
 // raw_rev[seg][m-1-i] = p_(i) / ((i+1)/m)
 __global__ void __launch_bounds__(256) bh_raw_kernel(const uint64_t* __restrict__ sorted, int64_t m, int64_t total,
                                                      uint64_t* __restrict__ raw_rev) {
@@ -164,6 +213,33 @@ extern "C" int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double
     SD_HIP(hipSetDevice(ctx->device));
     SD_TRY(ctx->arena.reserve((size_t)m * 37 + (size_t)(m / 3072 + 2) * 1024 + (1 << 16), ctx->stream));
     return bh_segments(ctx, m, 1, d_p, d_q);
+}
+
+extern "C" int sdice_bh_masked_dev(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, double* d_q) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_ARG(n >= 0 && n < ((int64_t)1 << 32), "n out of range");
+    if (n == 0) return SDICE_OK;
+    SD_ARG(d_p && d_q, "NULL pointer");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_TRY(ctx->arena.reserve((size_t)n * 37 + (size_t)(n / 3072 + 2) * 1024 + (1 << 16), ctx->stream));
+    Arena& A = ctx->arena;
+    const size_t M = (size_t)n;
+    uint64_t* kA = (uint64_t*)A.alloc(M * 8);
+    uint64_t* kB = (uint64_t*)A.alloc(M * 8);
+    uint64_t* kC = (uint64_t*)A.alloc(M * 8);
+    uint32_t* vA = (uint32_t*)A.alloc(M * 4);
+    uint32_t* vB = (uint32_t*)A.alloc(M * 4);
+    uint32_t* vC = (uint32_t*)A.alloc(M * 4);
+    unsigned long long* m_eff = (unsigned long long*)A.alloc(8);
+    if (!kA || !kB || !kC || !vA || !vB || !vC || !m_eff) return SDICE_ERR_NOMEM;
+    SD_HIP(hipMemsetAsync(m_eff, 0, 8, ctx->stream));
+    const unsigned g = (unsigned)sd_ceil_div(n, 256);
+    SD_LAUNCH(ctx, "bh_keys_masked_kernel", bh_keys_masked_kernel, dim3(g), dim3(256), 0, d_p, d_tested, n, kA, vA, m_eff);
+    SD_TRY(sd_radix_sort_pairs(ctx, n, kA, vA, kB, vB, kC, vC, ~0ull));
+    SD_LAUNCH(ctx, "bh_raw_masked_kernel", bh_raw_masked_kernel, dim3(g), dim3(256), 0, kB, n, m_eff, kA);
+    SD_TRY(sd_inclusive_min_scan_u64(ctx, n, kA, kC));
+    SD_LAUNCH(ctx, "bh_scatter_masked_kernel", bh_scatter_masked_kernel, dim3(g), dim3(256), 0, kC, vB, n, m_eff, d_q);
+    return SDICE_OK;
 }
 
 extern "C" int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q) {

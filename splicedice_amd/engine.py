@@ -42,6 +42,14 @@ class DeviceArray:
         check(self.ctx.lib.sdice_d2h(self.ctx.h, _ptr(out), self.ptr, self.nbytes), "sdice_d2h")
         return out
 
+    def memset(self, byte):
+        """fill with one byte value (async on the context stream); returns self"""
+        check(self.ctx.lib.sdice_dmemset(self.ctx.h, self.ptr, int(byte), self.nbytes), "sdice_dmemset")
+        return self
+
+    def zero(self):
+        return self.memset(0)
+
     def offset(self, n_elems_lead, shape):
         """View starting n_elems_lead elements in (not owned)."""
         return DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr + n_elems_lead * self.dtype.itemsize, owned=False)
@@ -292,6 +300,11 @@ class Context:
     def bh_columns_dev(self, d_p):
         n, cols = d_p.shape
         check(self.lib.sdice_bh_columns_dev(self.h, n, cols, d_p.ptr), "sdice_bh_columns_dev")
+
+    def bh_masked_dev(self, d_p, d_tested, d_q):
+        """BH over the present entries (tested != 0, or p >= 0 when d_tested is None); absent -> 0"""
+        check(self.lib.sdice_bh_masked_dev(self.h, int(np.prod(d_p.shape)), d_p.ptr,
+                                           d_tested.ptr if d_tested is not None else None, d_q.ptr), "sdice_bh_masked_dev")
 
     def bh_dev(self, d_p, d_q):
         check(self.lib.sdice_bh_dev(self.h, d_p.shape[0], d_p.ptr, d_q.ptr), "sdice_bh_dev")

@@ -77,10 +77,18 @@ def _union_packed(ctx, recs):
                       | rec["strand"][a].astype(np.int64)).astype(np.uint64))
     if not parts:
         return tuple(np.zeros(0, d) for d in (np.int32, np.int32, np.int32, np.int8))
-    keys = ctx.sort_unique_u64(np.concatenate(parts)).astype(np.int64)
-    left = (keys >> (_SPAN_BITS + 1)) & ((1 << _LEFT_BITS) - 1)
-    return ((keys >> (_LEFT_BITS + _SPAN_BITS + 1)).astype(np.int32), left.astype(np.int32),
-            (left + ((keys >> 1) & ((1 << _SPAN_BITS) - 1))).astype(np.int32), (keys & 1).astype(np.int8))
+    return _unpack_keys(ctx.sort_unique_u64(np.concatenate(parts)))
+
+
+def _unpack_keys(keys):
+    """packed uint64 keys -> (chrom_rank, left, right, strand).  Decoded as UNSIGNED words: chromosome
+    ranks >= 2048 set bit 63, which an int64 arithmetic shift would smear into a negative rank."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    u = np.uint64
+    left = (keys >> u(_SPAN_BITS + 1)) & u((1 << _LEFT_BITS) - 1)
+    span = (keys >> u(1)) & u((1 << _SPAN_BITS) - 1)
+    return ((keys >> u(_LEFT_BITS + _SPAN_BITS + 1)).astype(np.int32), left.astype(np.int32),
+            (left + span).astype(np.int32), (keys & u(1)).astype(np.int8))
 
 
 def ingest(manifest, args, ctx=None):

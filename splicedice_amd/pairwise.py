@@ -71,6 +71,8 @@ def add_parser(parser):
 
 
 def run_with(args, ctx=None):
+    from . import mgpu
+    L = mgpu.launcher()             # (reads the torchrun environment before any GPU call)
     if args.filter_list is not None:
         with open(args.filter_list, "r") as fh:
             filter_list = set(line.rstrip() for line in fh)
@@ -91,7 +93,28 @@ def run_with(args, ctx=None):
         print(f"[{n} / {totaln}] events analyzed...")
 
     own_ctx = ctx is None
-    ctx = ctx if ctx is not None else Context(0)
+    ctx = ctx if ctx is not None else Context(L.local_rank)
+    header = "clusterID\t" + "\t".join(columns) + "\n"
+    if L.world > 1 and totaln and pairs and not args.chi2:
+        # junction rows sharded over the ranks (distributed.pairwise_sharded); every rank formats its own
+        # rows, rank 0 stitches the parts into the one output table
+        from . import distributed
+        try:
+            row_ptr, col = exclusion_csr(events, clusters)
+            out = distributed.pairwise_sharded(ctx, L.comm(ctx), np.ascontiguousarray(counts, dtype=np.int32), row_ptr, col,
+                                               args.multiple_test_correction)
+        finally:
+            if own_ctx:
+                ctx.close()
+        lo, hi = out["own"]
+        textio.write_table(L.part(args.output), header if L.root else "", events[lo:hi],
+                           np.asarray(out["p"], dtype=np.float64).reshape(hi - lo, len(pairs)), "repr")
+        L.stitch(args.output)
+        return
+    if not L.root:
+        if own_ctx:
+            ctx.close()
+        return                       # (--chi2 and empty inputs are not sharded: rank 0 alone)
     try:
         row_ptr, col = exclusion_csr(events, clusters)
         if totaln and pairs:
@@ -116,7 +139,7 @@ def run_with(args, ctx=None):
             ctx.close()
 
     # str(numpy.float64) per cell (pairwise_fisher.py:195-200) through the library's formatter
-    textio.write_table(args.output, "clusterID\t" + "\t".join(columns) + "\n", events,
+    textio.write_table(args.output, header, events,
                        np.asarray(parray, dtype=np.float64).reshape(len(events), len(pairs)), "repr")
 
 

@@ -167,7 +167,9 @@ class Quant:
         self.manifestFilename = manifest_filename
         self.outputPrefix = output_prefix
         own_ctx = ctx is None
-        self.ctx = ctx if ctx is not None else Context(0)
+        from . import mgpu
+        self.L = mgpu.launcher()            # (reads the torchrun environment before any GPU call)
+        self.ctx = ctx if ctx is not None else Context(self.L.local_rank)
         try:
             self._run()
         finally:
@@ -197,12 +199,26 @@ class Quant:
         self.names = [textio.junction_name(j) for j in self.junctions]
         print("\tDone", timer.check())
 
+        # Several ranks (python -m torch.distributed.run ... -m splicedice_amd quant): parsing and clustering
+        # are repeated on every rank (host-bound, deterministic); the junction rows are then cut by
+        # shard.shard_plan and every rank computes and FORMATS its own rows of the two big tables;
+        # rank 0 writes the small files and stitches the parts (mgpu.py).
+        L = self.L
+        n = len(self.names)
+        if L.world > 1:
+            from . import shard
+            self.part = shard.shard_plan(self.row_ptr, self.col, L.world)[L.rank]
+        else:
+            self.part = dict(own_lo=0, own_hi=n, ext_lo=0, ext_hi=n)
+
         print("Writing cluster file...")
-        self.write_clusters()
+        if L.root:
+            self.write_clusters()
         print("\tDone", timer.check())
 
         print("Writing junction bed file...")
-        self.write_junction_bed()
+        if L.root:
+            self.write_junction_bed()
         print("\tDone", timer.check())
 
         print("Gathering junction counts...")
@@ -214,9 +230,19 @@ class Quant:
         print("\tDone", timer.check())
 
         print("Calculating PS values...")
-        self.psi = self.ctx.ps(self.counts, self.row_ptr, self.col)
-        if self.args.lowCoverageNan and self.low.size:
-            self.psi = self.ctx.mark_low(self.psi, self.low)
+        lo, hi, elo, ehi = (self.part[k] for k in ("own_lo", "own_hi", "ext_lo", "ext_hi"))
+        if L.world > 1:
+            from . import shard
+            rp, cl = shard.local_csr(self.row_ptr, self.col, self.part)
+            s = self.counts.shape[1]
+            self.psi = self.ctx.ps(np.ascontiguousarray(self.counts[elo:ehi]), rp, cl)[lo - elo: hi - elo] \
+                if hi > lo else np.zeros((0, s), np.float32)
+            low = self.low[(self.low // s >= lo) & (self.low // s < hi)] - lo * s if self.low.size else self.low
+        else:
+            self.psi = self.ctx.ps(self.counts, self.row_ptr, self.col)
+            low = self.low
+        if self.args.lowCoverageNan and low.size:
+            self.psi = self.ctx.mark_low(self.psi, low)
         print("\tDone", timer.check())
 
         print("Writing PS values...")
@@ -225,7 +251,8 @@ class Quant:
 
         if self.args.drim:
             print("Writing drim table...")
-            self.write_drim_table()
+            if L.root:
+                self.write_drim_table()
             print("\tDone", timer.check())
 
         print("All done", timer.total())
@@ -242,14 +269,25 @@ class Quant:
     def _sample_header(self, first):
         return first + "\t" + "\t".join(s.name for s in self.manifest) + "\n"
 
+    def _write_rows(self, path, data_own, mode):
+        """this rank's rows [own_lo, own_hi) of one table; with several ranks: part files, stitched by rank 0"""
+        L, lo, hi = self.L, self.part["own_lo"], self.part["own_hi"]
+        header = self._sample_header("cluster")
+        if L.world == 1:
+            textio.write_table(path, header, self.names, data_own, mode)
+            return
+        textio.write_table(L.part(path), header if L.root else "", self.names[lo:hi], data_own, mode)
+        L.stitch(path)
+
     def write_inclusions(self):
         # f'{x:.0f}' per cell (SPLICEDICE.py:340) through the library's multithreaded formatter
-        textio.write_table(f"{self.outputPrefix}_inclusionCounts.tsv", self._sample_header("cluster"), self.names,
-                           self.counts, ".0f")
+        lo, hi = self.part["own_lo"], self.part["own_hi"]
+        self._write_rows(f"{self.outputPrefix}_inclusionCounts.tsv", self.counts if self.L.world == 1 else self.counts[lo:hi],
+                         ".0f")
 
     def write_all_psi(self):
         # f'{x:.3f}' per cell (SPLICEDICE.py:353)
-        textio.write_table(f"{self.outputPrefix}_allPS.tsv", self._sample_header("cluster"), self.names, self.psi, ".3f")
+        self._write_rows(f"{self.outputPrefix}_allPS.tsv", self.psi, ".3f")
 
     def write_drim_table(self):
         counts_str = self.counts.astype(np.float32).astype("str")

@@ -81,6 +81,33 @@ def make_counts(n, s, seed, mean=30.0, disp=0.5, zero_frac=0.2, chunk=1 << 18):
     return out
 
 
+def make_counts_rows(lo, hi, s, seed, block=1 << 16, **kw):
+    """rows [lo, hi) of a count table that is defined block by block (one seeded block of `block`
+    rows each), so that any rank can generate exactly its own row range of ONE shared dataset."""
+    out = np.empty((hi - lo, s), dtype=np.int32)
+    for b in range(lo // block, (max(hi, lo + 1) - 1) // block + 1):
+        a0, a1 = b * block, (b + 1) * block
+        r0, r1 = max(lo, a0), min(hi, a1)
+        if r1 > r0:
+            blk = make_counts(block, s, (seed, b), **kw)
+            out[r0 - lo: r1 - lo] = blk[r0 - a0: r1 - a0]
+    return out
+
+
+def chrom_ranges(chrom_rank, world):
+    """contiguous chromosome ranges with near-equal junction counts -> [(c_lo, c_hi, row_lo, row_hi)] per rank:
+    rows are in (chrom, ...) order, so a chromosome range is a row range and no overlap edge crosses it"""
+    cnt = np.bincount(np.asarray(chrom_rank, dtype=np.int64))
+    cum = np.concatenate([[0], np.cumsum(cnt)])
+    n = int(cum[-1])
+    bounds = [0]
+    for k in range(1, world):
+        j = int(np.argmin(np.abs(cum - k * n / world)))
+        bounds.append(max(j, bounds[-1]))
+    bounds.append(cnt.size)
+    return [(bounds[k], bounds[k + 1], int(cum[bounds[k]]), int(cum[bounds[k + 1]])) for k in range(world)]
+
+
 def make_ps_matrix(n, s, seed, shift_frac=0.05, nan_frac=0.05, g1=None):
     """float32 [n, s] PS-like table for compare_sample_sets.
 

@@ -232,3 +232,31 @@ def test_quant_edge_cases_host_side(golden_dir, tmp_path, variant):
     assert got_names == bed
     counts2, _ = juncio.gather_counts(manifest, parsed, junc, args)
     assert [[str(int(x)) for x in row] for row in counts2] == want_counts
+
+
+def test_union_key_decoding_above_2047_chromosomes():
+    """ranks 2048..4095 set bit 63 of the packed key; they must not decode negative"""
+    from splicedice_amd import juncio
+    c = np.array([5, 2047, 2048, 4095], dtype=np.int64)
+    l = np.array([10, 2 ** 31 - 1 - 1000, 7, 123456], dtype=np.int64)
+    span = np.array([50, 999, (1 << 20) - 1, 0], dtype=np.int64)
+    st = np.array([0, 1, 1, 0], dtype=np.int64)
+    keys = ((c << 52) | (l << 21) | (span << 1) | st).astype(np.uint64)
+    cr, left, right, strand = juncio._unpack_keys(keys)
+    assert cr.tolist() == c.tolist() and left.tolist() == l.tolist()
+    assert right.tolist() == (l + span).tolist() and strand.tolist() == st.tolist()
+
+
+def test_strong_scaling_partition_helpers():
+    from splicedice_amd import synth
+    cr, l, r, st = synth.make_junctions(20000, 2)
+    for world in (1, 2, 3, 8):
+        rng_ = synth.chrom_ranges(cr, world)
+        assert rng_[0][2] == 0 and rng_[-1][3] == cr.size
+        for (c0, c1, r0, r1), nxt in zip(rng_, rng_[1:] + [None]):
+            assert r1 - r0 == int(((cr >= c0) & (cr < c1)).sum())
+            if nxt:
+                assert nxt[0] == c1 and nxt[2] == r1
+    a = synth.make_counts_rows(70000, 140001, 3, 5)
+    b = synth.make_counts_rows(0, 140001, 3, 5)
+    assert np.array_equal(a, b[70000:])

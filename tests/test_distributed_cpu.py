@@ -55,8 +55,13 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from splicedice_amd import shard
         counts, row_ptr, col, g1, g2 = _problem()
-        out = distributed.quant_compare_sharded(OracleEngine(), distributed.GlooComm(), counts, row_ptr, col, g1, g2)
+        comm = distributed.GlooComm()
+        part = shard.shard_plan(row_ptr, col, world)[rank]
+        mine = counts[part["ext_lo"]:part["ext_hi"]].copy()      # a rank is handed ITS rows only
+        del counts
+        out = distributed.quant_compare_sharded(OracleEngine(), comm, mine, row_ptr, col, g1, g2)
         q.put((rank, {k: v for k, v in out.items() if k != "plan"}, out["plan"]))
     finally:
         dist.destroy_process_group()
@@ -108,10 +113,14 @@ def _pairwise_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from splicedice_amd import shard
         counts, row_ptr, col = _pairwise_problem()
+        part = shard.shard_plan(row_ptr, col, world)[rank]
+        mine = counts[part["ext_lo"]:part["ext_hi"]].copy()      # a rank is handed ITS rows only
+        del counts
         res = {}
-        for mode in ("pairwise", "none"):
-            out = distributed.pairwise_sharded(OracleEngine(), distributed.GlooComm(), counts, row_ptr, col, mode)
+        for mode in ("pairwise", "none", "all"):
+            out = distributed.pairwise_sharded(OracleEngine(), distributed.GlooComm(), mine, row_ptr, col, mode)
             res[mode] = (out["own"], out["p"])
         q.put((rank, res))
     finally:
@@ -128,11 +137,11 @@ def test_sharded_pairwise_column_bh_equals_single_process():
     counts, row_ptr, col = _pairwise_problem()
     _, excl = O.calculate_psi_vectorised(counts, row_ptr, col)
     raw = O.fisher_pairs(counts, excl)
-    want = {"none": raw, "pairwise": O.bh_columns(raw)}
+    want = {"none": raw, "pairwise": O.bh_columns(raw), "all": O.bh_fdr(raw.reshape(-1)).reshape(raw.shape)}
     single = distributed.pairwise_sharded(OracleEngine(), distributed.SingleComm(), counts, row_ptr, col, "pairwise")
     assert single["own"] == (0, counts.shape[0]) and np.array_equal(single["p"], want["pairwise"])
-    with pytest.raises(NotImplementedError):
-        distributed.pairwise_sharded(OracleEngine(), distributed.SingleComm(), counts, row_ptr, col, "all")
+    single_all = distributed.pairwise_sharded(OracleEngine(), distributed.SingleComm(), counts, row_ptr, col, "all")
+    assert np.array_equal(single_all["p"], want["all"])
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -147,9 +156,68 @@ def test_sharded_pairwise_column_bh_equals_single_process():
         assert p.exitcode == 0
     covered = 0
     for rank, res in results:
-        for mode in ("pairwise", "none"):
+        for mode in ("pairwise", "none", "all"):
             (lo, hi), got = res[mode]
             assert np.array_equal(got, want[mode][lo:hi]), (rank, mode)
         covered += res["none"][0][1] - res["none"][0][0]
     assert covered == counts.shape[0]
     assert distributed.pair_column_ranges(15, 4) == [(0, 3), (3, 7), (7, 11), (11, 15)]
+
+
+# ---------------------------------------------------------------- sub-commands under a 2-rank launcher
+def _cli_worker(rank, world, port, which, outdir, golden):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import argparse
+    from splicedice_amd import compare_sample_sets, pairwise
+    eng = OracleEngine()
+    if which == "compare":
+        d = os.path.join(golden, "compare")
+        ns = argparse.Namespace(psiSPLICEDICE=os.path.join(d, "in_allPS.tsv"), manifest1=os.path.join(d, "m1.tsv"),
+                                manifest2=os.path.join(d, "m2.tsv"), annotation="", outputFile=os.path.join(outdir, "out.tsv"))
+        compare_sample_sets.run_with(ns, ctx=eng)
+    else:
+        d = os.path.join(golden, "pairwise")
+        for mode in ("pairwise", "all", "none"):
+            ns = argparse.Namespace(inclusionSPLICEDICE=os.path.join(d, "in_inclusionCounts.tsv"),
+                                    clusters=os.path.join(d, "in_allClusters.tsv"), chi2=False,
+                                    multiple_test_correction=mode, filter_list=None, output=os.path.join(outdir, f"{mode}.tsv"))
+            pairwise.run_with(ns, ctx=eng)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("which", ["compare", "pairwise"])
+def test_subcommands_under_two_rank_launcher(which, tmp_path, golden_dir):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m splicedice_amd <subcommand>`: both ranks run the
+    sub-command on their rows, ONE set of output files appears, equal to the reference-generated goldens
+    (the compute engine is the oracle-backed double; the real engine takes the same path with RcclComm)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    procs = [mpctx.Process(target=_cli_worker, args=(r, 2, port, which, str(tmp_path), golden_dir)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    def cells(path):
+        with open(path) as fh:
+            return [line.rstrip("\n").split("\t") for line in fh]
+    if which == "compare":
+        got, want = cells(tmp_path / "out.tsv"), cells(os.path.join(golden_dir, "compare", "expected_out.tsv"))
+        assert [g[0] for g in got] == [w[0] for w in want] and got[0] == want[0]
+        for g, w in zip(got[1:], want[1:]):
+            assert g[1:6] == w[1:6]                                              # float32 cells: string-identical
+            np.testing.assert_allclose([float(x) for x in g[6:]], [float(x) for x in w[6:]], rtol=1e-9)
+    else:
+        for mode in ("pairwise", "all", "none"):
+            got, want = cells(tmp_path / f"{mode}.tsv"), cells(os.path.join(golden_dir, "pairwise", f"expected_{mode}.tsv"))
+            assert [g[0] for g in got] == [w[0] for w in want] and got[0] == want[0]
+            for g, w in zip(got[1:], want[1:]):
+                np.testing.assert_allclose([float(x) for x in g[1:]], [float(x) for x in w[1:]], rtol=1e-9)
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]

@@ -41,8 +41,9 @@ def test_sharded_pipeline_on_engine_matches_oracle(ctx):
         full = O.calculate_psi_vectorised(counts, row_ptr, col)[0]
         assert np.array_equal(loc[a:b], full[part["own_lo"]:part["own_hi"]], equal_nan=True)
         # and the device-resident shard statistics (PS -> quantise -> rank-sum without leaving HBM)
-        st = distributed._shard_stats(ctx, np.ascontiguousarray(counts[part["ext_lo"]:part["ext_hi"]]), rp, cl, a, b - a,
-                                      g1, g2)
+        st = distributed.shard_stats(ctx, np.ascontiguousarray(counts[part["ext_lo"]:part["ext_hi"]]), rp, cl, a, b - a,
+                                     g1, g2)
+        st = {k_: v.to_host() for k_, v in st.items()}
         sl = slice(part["own_lo"], part["own_hi"])
         tt = want["tested"][sl].astype(bool)
         assert np.array_equal(st["tested"], want["tested"][sl]) and np.array_equal(st["z"][tt], want["z"][sl][tt])
@@ -56,8 +57,9 @@ def test_rccl_world1_allgather():
     with Context(0) as c:
         comm = distributed.RcclComm(c, 0, 1, lambda b, n: b)
         table = np.arange(40, dtype=np.float64).reshape(5, 8)
-        got = comm.allgather_rows(table)
-        assert len(got) == 1 and np.array_equal(got[0], table)
+        assert np.array_equal(comm.allgather(table), table)
+        d = c.to_device(table)
+        assert np.array_equal(comm.allgather(d).to_host(), table)
 
 
 def test_sharded_pairwise_on_engine(ctx):
@@ -82,5 +84,7 @@ def test_sharded_pairwise_on_engine(ctx):
         comm = distributed.RcclComm(c, 0, 1, lambda b, n_: b)
         out2 = distributed.pairwise_sharded(c, comm, counts, row_ptr, col, "pairwise")
         assert np.array_equal(out2["p"], out["p"])
-        blocks = [np.arange(12, dtype=np.float64).reshape(3, 4)]
-        assert np.array_equal(comm.alltoall(blocks)[0], blocks[0])
+        blocks = np.arange(12, dtype=np.float64).reshape(1, 3, 4)
+        assert np.array_equal(comm.alltoall(blocks), blocks)
+        out3 = distributed.pairwise_sharded(c, comm, counts, row_ptr, col, "all")
+        np.testing.assert_allclose(out3["p"], O.bh_fdr(full_raw.reshape(-1)).reshape(full_raw.shape), rtol=1e-12, atol=0)
