@@ -117,3 +117,97 @@ def test_fisher_properties(ctx):
     for i in range(0, 200_000, 9973):
         w = fisher_exact(t[i].reshape(2, 2))[1]
         assert abs(p[i] - w) <= 1e-9 * w
+
+
+def test_pairwise_config4_shard_full_shape(ctx):
+    """BASELINE config 4, one GPU's shard: 25 000 junctions x 200 samples -> 19 900 pair columns, device resident.
+    Pair-index inversion up to the last column, column-wise BH properties, sampled cells against scipy."""
+    from scipy.stats import fisher_exact
+    n, s = 25_000, 200
+    pairs = s * (s - 1) // 2
+    cr, l, r, st = synth.make_junctions(n, 4)
+    row_of, row_ptr, col = ctx.cluster(cr, l, r, st)
+    counts_in = synth.make_counts(n, s, 40)
+    counts = np.zeros_like(counts_in)
+    counts[row_of] = counts_in
+    d_counts, d_rp, d_col = ctx.to_device(counts), ctx.to_device(row_ptr), ctx.to_device(col)
+    d_excl, d_p = ctx.empty((n, s), np.int64), ctx.empty((n, pairs), np.float64)
+    ctx.ps_dev(d_counts, d_rp, d_col, d_excl, None)
+    ctx.fisher_pairs_dev(d_counts, d_excl, d_p)
+    excl = d_excl.to_host()
+    _, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    assert np.array_equal(excl, want_excl)
+    rows = [0, 1, 12_345, n - 1]
+    raw = {rr: d_p.offset(rr * pairs, (pairs,)).to_host() for rr in rows}
+    def pair_index(i, j):
+        return i * s - i * (i + 1) // 2 + (j - i - 1)
+    assert pair_index(s - 2, s - 1) == pairs - 1
+    for rr in rows:
+        assert ((raw[rr] > 0) & (raw[rr] <= 1)).all()
+        for i, j in [(0, 1), (0, s - 1), (1, 2), (57, 133), (s - 3, s - 1), (s - 2, s - 1)]:     # first ... last column
+            w = fisher_exact([[counts[rr, i], counts[rr, j]], [excl[rr, i], excl[rr, j]]])[1]
+            assert abs(raw[rr][pair_index(i, j)] - w) <= 1e-9 * w, (rr, i, j)
+    # column-wise BH on the whole [25 000, 19 900] table, in place
+    cols_chk = [0, 1, 9_950, pairs - 2, pairs - 1]
+    def column(c):
+        out = ctx.empty((n,), np.float64)
+        ctx.copy2d_dev(out.ptr, 8, d_p.ptr + c * 8, pairs * 8, 8, n)
+        return out.to_host()
+    before = {c: column(c) for c in cols_chk}
+    ctx.bh_columns_dev(d_p)
+    for c in cols_chk:
+        q, p = column(c), before[c]
+        order = np.argsort(p, kind="stable")
+        assert (np.diff(q[order]) >= -1e-18).all() and (q >= p * (1 - 1e-15)).all() and (q <= 1).all()
+        np.testing.assert_allclose(q, O.bh_fdr(p), rtol=1e-12, atol=0)
+
+
+def test_e2e_config5_shard_full_shape(ctx):
+    """BASELINE config 5, one GPU's shard: 625 000 junctions x 1000 samples, 500 v 500, device resident:
+    cluster -> PS (quantise fused) -> rank-sum.  Group-swap antisymmetry on every row, sampled rows vs the oracle."""
+    n, s, blk = 625_000, 1000, 125_000
+    cr, l, r, st = synth.make_junctions(n, 5)
+    d_j = [ctx.to_device(x) for x in (cr, l, r, st)]
+    d_row_of, d_rp = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    d_col, nnz = ctx.cluster_dev(*d_j, d_row_of, d_rp)
+    block = synth.make_counts(blk, s, 50)
+    d_counts = ctx.empty((n, s), np.int32)
+    for a in range(0, n, blk):
+        d_counts.offset(a * s, (blk, s)).upload(block)
+    d_ps = ctx.empty((n, s), np.float32)
+    ctx.set_param("ps.quantize3", 1)
+    try:
+        ctx.ps_dev(d_counts, d_rp, d_col, None, d_ps)
+    finally:
+        ctx.set_param("ps.quantize3", 0)
+    g1, g2 = np.arange(0, 500, dtype=np.int32), np.arange(500, 1000, dtype=np.int32)
+    d_g1, d_g2 = ctx.to_device(g1), ctx.to_device(g2)
+    def run(a, b):
+        out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
+                   med1=ctx.empty(n, np.float32), med2=ctx.empty(n, np.float32), mean1=ctx.empty(n, np.float32),
+                   mean2=ctx.empty(n, np.float32), delta=ctx.empty(n, np.float32))
+        ctx.ranksum_dev(d_ps, a, b, out)
+        return {k: v.to_host() for k, v in out.items()}
+    fwd, rev = run(d_g1, d_g2), run(d_g2, d_g1)
+    t = fwd["tested"].astype(bool)
+    assert np.array_equal(fwd["tested"], rev["tested"]) and t.mean() > 0.9
+    assert np.array_equal(fwd["z"][t], -rev["z"][t]) and np.array_equal(fwd["p"][t], rev["p"][t])
+    assert np.array_equal(fwd["med1"], rev["med2"]) and np.array_equal(fwd["mean2"], rev["mean1"])
+    assert np.array_equal(fwd["delta"][t], -rev["delta"][t])
+    # sampled rows against the oracle, on the device's own PS rows (rows 0.., a block seam, the last rows)
+    for lo in (0, blk - 150, n - 300):
+        ps = d_ps.offset(lo * s, (300, s)).to_host()
+        want = O.compare_rows(ps, g1, g2)
+        tt = want["tested"].astype(bool)
+        sl = slice(lo, lo + 300)
+        assert np.array_equal(fwd["tested"][sl], want["tested"]) and np.array_equal(fwd["z"][sl][tt], want["z"][tt])
+        for k in ("med1", "med2", "mean1", "mean2", "delta"):
+            assert np.array_equal(fwd[k][sl][tt], want[k][tt]), k
+        np.testing.assert_allclose(fwd["p"][sl][tt], want["p"][tt], rtol=1e-9, atol=0)
+    # and the PS rows themselves where every neighbour row is at hand: first rows of the table
+    rp = d_rp.to_host()[:4001]
+    cl = d_col.to_host()[: int(rp[-1])]
+    inside = np.array([(cl[rp[i]:rp[i + 1]] < 4000).all() for i in range(300)])
+    want_ps, _ = O.calculate_psi_vectorised(block[:4000], rp, np.minimum(cl, 3999))
+    got = d_ps.offset(0, (300, s)).to_host()
+    assert np.array_equal(got[inside], O.quantize3_fast(want_ps[:300])[inside], equal_nan=True)
