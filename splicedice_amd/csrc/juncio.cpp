@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -72,16 +73,22 @@ inline bool to_f64(const char* a, const char* b, double& v) {
 
 }  // namespace
 
-extern "C" int sdice_junc_close(sdice_juncfile* t) {
+extern "C" int sdice_junc_close(sdice_juncfile* t) try {
     if (!t) return SDICE_OK;
     if (t->base && t->size) munmap((void*)t->base, t->size);
     if (t->fd >= 0) close(t->fd);
     delete t;
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junc_close: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junc_close: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 extern "C" int sdice_junc_open(const char* path, int type, sdice_juncfile** out, int64_t* n_lines, int32_t* n_chroms,
-                               int64_t* chrom_bytes) {
+                               int64_t* chrom_bytes) try {
     if (!path || !out || type < 0 || type > 2) { sdice_set_error("sdice_junc_open: bad arguments"); return SDICE_ERR_ARG; }
     *out = nullptr;
     sdice_juncfile* t = new sdice_juncfile();
@@ -145,6 +152,12 @@ extern "C" int sdice_junc_open(const char* path, int type, sdice_juncfile** out,
     if (chrom_bytes) *chrom_bytes = bytes;
     *out = t;
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junc_open: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junc_open: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // Fills, per line: chrom_id (index into the file's chromosome table), left, right, strand code
@@ -153,7 +166,7 @@ extern "C" int sdice_junc_open(const char* path, int type, sdice_juncfile** out,
 extern "C" int sdice_junc_read(sdice_juncfile* t, int32_t min_length, int32_t max_length, int32_t min_unique,
                                int32_t min_overhang, double min_entropy, int no_multimap, int32_t* chrom_id,
                                int32_t* left, int32_t* right, int8_t* strand, int64_t* score, uint8_t* admit,
-                               char* chrom_names, int64_t* chrom_off, int threads) {
+                               char* chrom_names, int64_t* chrom_off, int threads) try {
     if (!t || (t->n > 0 && (!chrom_id || !left || !right || !strand || !score || !admit))) {
         sdice_set_error("sdice_junc_read: bad arguments");
         return SDICE_ERR_ARG;
@@ -219,12 +232,15 @@ extern "C" int sdice_junc_read(sdice_juncfile* t, int32_t min_length, int32_t ma
                         if (*q == ';') semi[ns++] = q;
                     if (ns < 3) { bad[tix] = i; return; }
                     // info[3][1]: text between the first ':' of the 4th item and the next ':' (or its end)
+                    // (the 4th item ends at the next ';' if the name carries more items, SPLICEDICE.py:190)
                     const char* a4 = semi[2] + 1;
-                    const char* c4 = (const char*)memchr(a4, ':', (size_t)(se - a4));
+                    const char* a4e = (const char*)memchr(a4, ';', (size_t)(se - a4));
+                    if (!a4e) a4e = se;
+                    const char* c4 = (const char*)memchr(a4, ':', (size_t)(a4e - a4));
                     if (!c4) { bad[tix] = i; return; }
                     const char* v4 = c4 + 1;
-                    const char* v4e = (const char*)memchr(v4, ':', (size_t)(se - v4));
-                    if (!v4e) v4e = se;
+                    const char* v4e = (const char*)memchr(v4, ':', (size_t)(a4e - v4));
+                    if (!v4e) v4e = a4e;
                     const bool unannotated = (v4e - v4 == 1 && *v4 == '?');
                     if (unannotated) {
                         // info[0] = e:<Lent>:<Rent>, info[1] = o:<overhang>
@@ -269,13 +285,19 @@ extern "C" int sdice_junc_read(sdice_juncfile* t, int32_t min_length, int32_t ma
         return SDICE_ERR_ARG;
     }
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junc_read: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junc_read: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // Row of every query junction in a table of rows sorted by (chrom, left, right, strand); -1 if absent.
 extern "C" int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const int32_t* row_left,
                                  const int32_t* row_right, const int8_t* row_strand, int64_t n_q,
                                  const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
-                                 const int8_t* q_strand, int32_t* row_out, int threads) {
+                                 const int8_t* q_strand, int32_t* row_out, int threads) try {
     if (n_rows < 0 || n_q < 0 || (n_q > 0 && !row_out)) { sdice_set_error("sdice_junc_lookup: bad arguments"); return SDICE_ERR_ARG; }
     int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (nthreads < 1) nthreads = 1;
@@ -308,4 +330,10 @@ extern "C" int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const
         for (auto& th : pool) th.join();
     }
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junc_lookup: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junc_lookup: unknown exception");
+    return SDICE_ERR_STATE;
 }

@@ -9,11 +9,13 @@
 //                                      positional for 1e-4 <= |x| < 1e16, else d.ddde+XX)
 // and with its readers (numpy string -> float64 -> dtype; compareSampleSets.py:202,
 // pairwise_fisher.py:60, counts_to_ps.py:50).  No device code here.
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -132,7 +134,7 @@ void parallel_rows(int64_t n, int threads, F&& fn) {
 // mode: 0 = '%.3f', 1 = '%.0f', 2 = numpy str() shortest repr
 // dtype: 0 = float32, 1 = float64, 2 = int32 (mode 1 only)
 extern "C" int sdice_write_table(const char* path, const char* header, int64_t n, int32_t s, const char* names,
-                                 const int64_t* name_off, const void* data, int dtype, int mode, int threads) {
+                                 const int64_t* name_off, const void* data, int dtype, int mode, int threads) try {
     if (!path || !header || n < 0 || s < 0 || (n > 0 && (!names || !name_off || (!data && s > 0)))) {
         sdice_set_error("sdice_write_table: bad arguments");
         return SDICE_ERR_ARG;
@@ -195,13 +197,19 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
         return SDICE_ERR_ARG;
     }
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_write_table: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_write_table: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // Column-major variant: every column has its own array, dtype and mode (the compare_sample_sets
 // output mixes float32 and float64 numpy-repr columns, compareSampleSets.py:252-270).
 extern "C" int sdice_write_columns(const char* path, const char* header, int64_t n, const char* names,
                                    const int64_t* name_off, int32_t ncols, const void* const* cols,
-                                   const int32_t* dtypes, const int32_t* modes, int threads) {
+                                   const int32_t* dtypes, const int32_t* modes, int threads) try {
     if (!path || !header || n < 0 || ncols < 0 || (n > 0 && (!names || !name_off)) || (ncols > 0 && (!cols || !dtypes || !modes))) {
         sdice_set_error("sdice_write_columns: bad arguments");
         return SDICE_ERR_ARG;
@@ -263,12 +271,18 @@ extern "C" int sdice_write_columns(const char* path, const char* header, int64_t
         return SDICE_ERR_ARG;
     }
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_write_columns: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_write_columns: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // `_allClusters.tsv` (SPLICEDICE.py:316-326): one line per junction row,
 // name<TAB>name_of_neighbour_1,name_of_neighbour_2,...  (a junction without overlaps: name<TAB>).
 extern "C" int sdice_write_clusters(const char* path, int64_t n, const char* names, const int64_t* name_off,
-                                    const int64_t* row_ptr, const int32_t* col, int threads) {
+                                    const int64_t* row_ptr, const int32_t* col, int threads) try {
     if (!path || n < 0 || (n > 0 && (!names || !name_off || !row_ptr)) || (n > 0 && row_ptr[n] > 0 && !col)) {
         sdice_set_error("sdice_write_clusters: bad arguments");
         return SDICE_ERR_ARG;
@@ -286,7 +300,7 @@ extern "C" int sdice_write_clusters(const char* path, int64_t n, const char* nam
         int used = nb < 4096 ? 1 : std::min(nthreads, 64);
         if (used < 1) used = 1;
         bufs.assign(used, std::string());
-        bool bad = false;
+        std::atomic<bool> bad{false};       // (set by any worker thread)
         parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
             std::string& out = bufs[t];
             for (int64_t r = r0 + a; r < r0 + b; ++r) {
@@ -318,6 +332,12 @@ extern "C" int sdice_write_clusters(const char* path, int64_t n, const char* nam
         return SDICE_ERR_ARG;
     }
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_write_clusters: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_write_clusters: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // ------------------------------------------------------------------------------------------ reader
@@ -333,18 +353,24 @@ struct sdice_table {
     int rstrip_mode = 0;
 };
 
-extern "C" int sdice_table_close(sdice_table* t) {
+extern "C" int sdice_table_close(sdice_table* t) try {
     if (!t) return SDICE_OK;
     if (t->base && t->size) munmap((void*)t->base, t->size);
     if (t->fd >= 0) close(t->fd);
     delete t;
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_table_close: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_table_close: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // Opens a table and indexes its lines.  n = data lines, s = tab-separated value columns of the
 // header (= header fields - 1), names_bytes = total length of the first field of every line.
 extern "C" int sdice_table_open(const char* path, sdice_table** out, int64_t* n, int32_t* s, int64_t* names_bytes,
-                                int64_t* header_bytes) {
+                                int64_t* header_bytes) try {
     if (!path || !out) { sdice_set_error("sdice_table_open: bad arguments"); return SDICE_ERR_ARG; }
     *out = nullptr;
     sdice_table* t = new sdice_table();
@@ -399,13 +425,19 @@ extern "C" int sdice_table_open(const char* path, sdice_table** out, int64_t* n,
     if (header_bytes) *header_bytes = (int64_t)t->body;
     *out = t;
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_table_open: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_table_open: unknown exception");
+    return SDICE_ERR_STATE;
 }
 
 // Fills header (header_bytes incl. newline, not NUL terminated), names blob + offsets[n+1] and
 // data[n, s] (dtype 0 float32, 1 float64; numpy semantics: text -> float64 -> dtype).
 // A line with a different number of fields than the header is an error, as numpy would raise.
 extern "C" int sdice_table_read(sdice_table* t, char* header, char* names, int64_t* name_off, void* data, int dtype,
-                                int threads) {
+                                int threads) try {
     if (!t || (t->n > 0 && (!names || !name_off || (!data && t->s > 0))) || dtype < 0 || dtype > 1) {
         sdice_set_error("sdice_table_read: bad arguments");
         return SDICE_ERR_ARG;
@@ -463,4 +495,10 @@ extern "C" int sdice_table_read(sdice_table* t, char* header, char* names, int64
             return SDICE_ERR_ARG;
         }
     return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_table_read: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_table_read: unknown exception");
+    return SDICE_ERR_STATE;
 }
