@@ -176,7 +176,8 @@ int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_in
  *      (text -> float64 -> dtype: compareSampleSets.py:202, pairwise_fisher.py:60, counts_to_ps.py:50).
  *  Tables are  header-line '\n'  then one line per row:  name '\t' v '\t' v ... '\n'.
  *  names: concatenated row names, name_off[n+1] byte offsets into it.
- *  dtype 0 float32, 1 float64, 2 int32;  mode 0 '%.3f', 1 '%.0f', 2 numpy str() shortest repr. */
+ *  dtype 0 float32, 1 float64, 2 int32;  mode 0 '%.3f', 1 '%.0f', 2 numpy str() shortest repr;
+ *  mode | 0x100 appends to an existing file (tables streamed in row slabs). */
 int sdice_write_table(const char* path, const char* header /* incl. '\n' */, int64_t n, int32_t s,
                       const char* names, const int64_t* name_off, const void* data, int dtype, int mode,
                       int threads /* 0 = all cores */);

@@ -166,14 +166,34 @@ __global__ void __launch_bounds__(256) transpose_f64_kernel(const double* __rest
     }
 }
 
-int transpose(sdice_ctx* ctx, const double* in, int64_t rows, int64_t cols, double* out) {
-    const int64_t gx = sd_ceil_div(cols, 32), gy = sd_ceil_div(rows, 32);
-    if (gy > 65535) {
-        sdice_set_error("transpose: more than 2097120 rows per call");
-        return SDICE_ERR_ARG;
+// out[c, r] = in[r, c] for an in of `rows` x `cols` with row pitch in_pitch, out row pitch out_pitch (elements)
+__global__ void __launch_bounds__(256) transpose_f64_pitched_kernel(const double* __restrict__ in, int64_t rows, int64_t cols,
+                                                                    int64_t in_pitch, double* __restrict__ out,
+                                                                    int64_t out_pitch) {
+    __shared__ double tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = r0 + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[k][tx] = in[r * in_pitch + c];
     }
-    SD_LAUNCH(ctx, "transpose_f64_kernel", transpose_f64_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, in, rows, cols,
-              out);
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) out[c * out_pitch + r] = tile[tx][k];
+    }
+}
+
+int transpose(sdice_ctx* ctx, const double* in, int64_t rows, int64_t cols, double* out) {
+    // the grid's y extent is limited to 65535 blocks: tall matrices go in row chunks
+    const int64_t chunk = (int64_t)65535 * 32;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const int64_t rc = std::min(chunk, rows - r0);
+        const int64_t gx = sd_ceil_div(cols, 32), gy = sd_ceil_div(rc, 32);
+        if (gx > 0x7fffffff) { sdice_set_error("transpose: too many columns"); return SDICE_ERR_ARG; }
+        SD_LAUNCH(ctx, "transpose_f64_kernel", transpose_f64_pitched_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
+                  in + r0 * cols, rc, cols, cols, out + r0, rows);
+    }
     return SDICE_OK;
 }
 
@@ -262,12 +282,17 @@ extern "C" int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q) {
 extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n >= 0 && cols >= 0, "negative size");
-    SD_ARG(n <= 2000000, "more than 2 000 000 rows per column is not supported (transpose grid limit)");
     if (n == 0 || cols == 0) return SDICE_OK;
     SD_ARG(d_p_inout, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
-    const int64_t budget = (int64_t)48 << 30;                    // scratch bytes per group of columns
-    int64_t group = budget / (n * 44) > 0 ? budget / (n * 44) : 1;   // 2 x 8 (transposed in/out) + 28 sort scratch
+    // columns per group from what is free right now: per value 2 x 8 B (transposed in / out) + 8 B (dense slab
+    // when the columns go in groups) + 37 B of sort scratch + histograms; a failed reservation halves the group
+    size_t free_b = 0, total_b = 0;
+    SD_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t arena_b = 0;
+    for (auto& c : ctx->arena.chunks) arena_b += c.cap;         // the arena's own chunk is reused
+    const int64_t budget = (int64_t)((free_b + arena_b) / 10 * 9);
+    int64_t group = budget / (n * 64) > 0 ? budget / (n * 64) : 1;
     if (group > cols) group = cols;
     if (group > 65535) group = 65535;
     int rc = SDICE_OK;
@@ -279,6 +304,12 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
         const size_t vals = (size_t)n * (size_t)group;
         rc = ctx->arena.reserve(vals * (16 + (group < cols ? 8 : 0) + 37) +
                                     (size_t)group * ((size_t)(n / 3072 + 2) * 1024 + 1024) + (1 << 16), ctx->stream);
+        if (rc == SDICE_ERR_NOMEM && group > 1) {            // less memory than hipMemGetInfo promised: fewer columns at once
+            group = (group + 1) / 2;
+            c0 -= group;                                      // (the loop increment adds it back: retry this column)
+            rc = SDICE_OK;
+            continue;
+        }
         if (rc != SDICE_OK) break;
         double* d_cm = (double*)ctx->arena.alloc(vals * 8);
         double* d_q = (double*)ctx->arena.alloc(vals * 8);

@@ -131,7 +131,8 @@ void parallel_rows(int64_t n, int threads, F&& fn) {
 
 }  // namespace
 
-// mode: 0 = '%.3f', 1 = '%.0f', 2 = numpy str() shortest repr
+// mode: 0 = '%.3f', 1 = '%.0f', 2 = numpy str() shortest repr; + 0x100: append to an existing file (a table
+//       streamed in row slabs -- `pairwise` at config-4 size writes 32 GB of p-values this way)
 // dtype: 0 = float32, 1 = float64, 2 = int32 (mode 1 only)
 extern "C" int sdice_write_table(const char* path, const char* header, int64_t n, int32_t s, const char* names,
                                  const int64_t* name_off, const void* data, int dtype, int mode, int threads) try {
@@ -139,11 +140,13 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
         sdice_set_error("sdice_write_table: bad arguments");
         return SDICE_ERR_ARG;
     }
+    const bool append = (mode & 0x100) != 0;
+    mode &= 0xff;
     if (dtype < 0 || dtype > 2 || mode < 0 || mode > 2 || (dtype == 2 && mode != 1)) {
         sdice_set_error("sdice_write_table: unsupported dtype/mode combination");
         return SDICE_ERR_ARG;
     }
-    FILE* fh = fopen(path, "wb");
+    FILE* fh = fopen(path, append ? "ab" : "wb");
     if (!fh) {
         sdice_set_error("sdice_write_table: cannot open %s", path);
         return SDICE_ERR_ARG;

@@ -297,6 +297,10 @@ class Context:
         n, s = d_incl.shape
         check(self.lib.sdice_fisher_pairs_dev(self.h, n, s, d_incl.ptr, d_excl.ptr, d_p.ptr), "sdice_fisher_pairs_dev")
 
+    def chi2_pairs_dev(self, d_incl, d_excl, d_p, d_n_bad):
+        n, s = d_incl.shape
+        check(self.lib.sdice_chi2_pairs_dev(self.h, n, s, d_incl.ptr, d_excl.ptr, d_p.ptr, d_n_bad.ptr), "sdice_chi2_pairs_dev")
+
     def bh_columns_dev(self, d_p):
         n, cols = d_p.shape
         check(self.lib.sdice_bh_columns_dev(self.h, n, cols, d_p.ptr), "sdice_bh_columns_dev")

@@ -56,6 +56,51 @@ def exclusion_csr(events, clusters):
     return row_ptr, np.asarray(col, dtype=np.int32)
 
 
+SLAB_BYTES = 256 << 20      # host memory of the streamed output (rows x pairs x 8 B per slab)
+
+
+def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header, path):
+    """exclusion sums -> per-pair test -> correction with the [n, pairs] p-value matrix RESIDENT IN HBM
+    (config 4: 200 000 x 19 900 doubles = 32 GB; the reference holds it in host memory,
+    pairwise_fisher.py:123-193), then streamed to the output table in row slabs: device -> host ->
+    formatter -> file, so host memory stays bounded by SLAB_BYTES whatever the table size."""
+    n, s = counts.shape
+    pairs = s * (s - 1) // 2
+    d_counts = ctx.to_device(counts, np.int32)
+    d_rp = ctx.to_device(row_ptr, np.int64)
+    d_col = ctx.to_device(col if col.size else np.zeros(1, np.int32), np.int32)
+    d_excl = ctx.empty((n, s), np.int64)
+    ctx.ps_dev(d_counts, d_rp, d_col, d_excl, None)
+    d_p = ctx.empty((n, pairs), np.float64)
+    if chi2:
+        d_bad = ctx.empty(1, np.int64)
+        ctx.chi2_pairs_dev(d_counts, d_excl, d_p, d_bad)
+        n_bad = int(d_bad.to_host()[0])
+        if n_bad:
+            # scipy.stats.chi2_contingency raises on the first such table and the reference
+            # run dies with it (pairwise_fisher.py:167-179)
+            raise ValueError("The internally computed table of expected frequencies has a zero element "
+                             f"({n_bad} of {n * pairs} sample-pair tables have an empty row or column)")
+    else:
+        ctx.fisher_pairs_dev(d_counts, d_excl, d_p)
+    for a in (d_counts, d_rp, d_col, d_excl):
+        a.free()
+    if correction == "all":
+        d_q = ctx.empty((n, pairs), np.float64)
+        ctx.bh_dev(d_p.offset(0, (n * pairs,)), d_q.offset(0, (n * pairs,)))
+        ctx.sync()
+        d_p.free()
+        d_p = d_q
+    elif correction == "pairwise":
+        ctx.bh_columns_dev(d_p)
+    slab = max(1, SLAB_BYTES // (pairs * 8))
+    for r0 in range(0, n, slab):
+        k = min(slab, n - r0)
+        textio.write_table(path, header if r0 == 0 else "", events[r0:r0 + k], d_p.offset(r0 * pairs, (k, pairs)).to_host(),
+                           "repr", append=r0 > 0)
+    d_p.free()
+
+
 def add_parser(parser):
     # same flags, defaults and choices as pairwise_fisher.py:71-111
     parser.add_argument("--inclusionSPLICEDICE", type=str, required=True,
@@ -115,7 +160,15 @@ def run_with(args, ctx=None):
         if own_ctx:
             ctx.close()
         return                       # (--chi2 and empty inputs are not sharded: rank 0 alone)
-    try:
+    if totaln and pairs and hasattr(ctx, "fisher_pairs_dev"):
+        try:
+            row_ptr, col = exclusion_csr(events, clusters)
+            device_pipeline(ctx, counts, row_ptr, col, args.chi2, args.multiple_test_correction, events, header, args.output)
+        finally:
+            if own_ctx:
+                ctx.close()
+        return
+    try:        # host-array engine (the CPU test double) and empty inputs
         row_ptr, col = exclusion_csr(events, clusters)
         if totaln and pairs:
             excl = ctx.ps(counts, row_ptr, col, want_excl=True, want_ps=False)

@@ -58,7 +58,7 @@ _DTYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int
 _MODE_CODE = {".3f": 0, ".0f": 1, "repr": 2}
 
 
-def write_table(path, header, names, data, mode, threads=0):
+def write_table(path, header, names, data, mode, threads=0, append=False):
     """Write `header` + one 'name<TAB>values' line per row through the library's multithreaded
     formatter (sdice_write_table).  mode: '.3f' | '.0f' | 'repr' (numpy str of float32/float64).
     Byte-identical to the reference's per-element f-string writers."""
@@ -77,7 +77,8 @@ def write_table(path, header, names, data, mode, threads=0):
         np.cumsum([len(b) for b in blobs], out=off[1:])
     blob = b"".join(blobs)
     rc = lib.sdice_write_table(str(path).encode(), header.encode(), n, s, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
-                               data.ctypes.data_as(C.c_void_p), _DTYPE_CODE[data.dtype], _MODE_CODE[mode], int(threads))
+                               data.ctypes.data_as(C.c_void_p), _DTYPE_CODE[data.dtype],
+                               _MODE_CODE[mode] | (0x100 if append else 0), int(threads))
     _ffi.check(rc, "sdice_write_table")
 
 
