@@ -241,6 +241,73 @@ __device__ __forceinline__ void bitonic_sort(E* buf, int count, int P, int t, in
     __syncthreads();
 }
 
+// The same network on 64-bit keys with FOUR elements per thread and TWO levels per pass: a group of
+// four elements that is closed under two consecutive levels is loaded once, exchanged in registers
+// and stored once -- half the LDS instructions of the one-level form (the sort is bound by the
+// LDS instruction rate: 2 reads + 2 writes per comparator there).
+//   pass A(k)  = flip(k) + disperse(k/4):  e0 = b+off, e1 = e0+k/4, e3 = b+k-1-off, e2 = e3-k/4
+//   pass B(j)  = disperse(j) + disperse(j/2): e0 = b+off, e1 = e0+j/2, e2 = e0+j, e3 = e0+3j/2
+//   pass C     = disperse(1) alone (also flip(2)): four consecutive elements
+// A wave's 64 groups lie in one 256-element segment of its own whenever the block size (k resp. 2j)
+// is <= 256: consecutive such passes need no workgroup barrier.
+__device__ __forceinline__ void ce64(uint64_t& a, uint64_t& b) {
+    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+
+template <int MODE>
+__device__ __forceinline__ void bitonic_pass4(uint64_t* buf, int count, int P, int t, int T, int param) {
+    const int lg = MODE == 0 ? __ffs(param >> 2) - 1 : MODE == 1 ? __ffs(param >> 1) - 1 : 0;
+    for (int g = t; g < (P >> 2); g += T) {
+        int e0, e1, e2, e3;
+        if (MODE == 0) {
+            const int q = param >> 2, off = g & (q - 1), b0 = (g >> lg) << (lg + 2);
+            e0 = b0 + off; e1 = e0 + q; e3 = b0 + param - 1 - off; e2 = e3 - q;
+        } else if (MODE == 1) {
+            const int h = param >> 1, off = g & (h - 1), b0 = (g >> lg) << (lg + 2);
+            e0 = b0 + off; e1 = e0 + h; e2 = e1 + h; e3 = e2 + h;
+        } else {
+            e0 = g << 2; e1 = e0 + 1; e2 = e0 + 2; e3 = e0 + 3;
+        }
+        if (e0 >= count) continue;                             // (e0 is the lowest index of the group)
+        uint64_t v0 = buf[e0];
+        uint64_t v1 = e1 < count ? buf[e1] : ~0ull, v2 = e2 < count ? buf[e2] : ~0ull, v3 = e3 < count ? buf[e3] : ~0ull;
+        if (MODE == 0) { ce64(v0, v3); ce64(v1, v2); ce64(v0, v1); ce64(v2, v3); }
+        else if (MODE == 1) { ce64(v0, v2); ce64(v1, v3); ce64(v0, v1); ce64(v2, v3); }
+        else { ce64(v0, v1); ce64(v2, v3); }
+        buf[e0] = v0;
+        if (e1 < count) buf[e1] = v1;
+        if (e2 < count) buf[e2] = v2;
+        if (e3 < count) buf[e3] = v3;
+    }
+}
+
+__device__ __forceinline__ void bitonic_sort_u64(uint64_t* buf, int count, int P, int t, int T) {
+    if (P < 4) P = 4;
+    bool prev_confined = false;
+    auto sync = [&](bool confined) {
+        if (confined && prev_confined) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        prev_confined = confined;
+    };
+    sync(true);
+    bitonic_pass4<2>(buf, count, P, t, T, 0);                  // k = 2
+    for (int k = 4; k <= P; k <<= 1) {
+        sync(k <= 256);
+        bitonic_pass4<0>(buf, count, P, t, T, k);              // flip(k), disperse(k/4)
+        int j = k >> 3;
+        while (j >= 2) {
+            sync(j <= 128);
+            bitonic_pass4<1>(buf, count, P, t, T, j);          // disperse(j), disperse(j/2)
+            j >>= 2;
+        }
+        if (j == 1) {
+            sync(true);
+            bitonic_pass4<2>(buf, count, P, t, T, 0);          // disperse(1)
+        }
+    }
+    __syncthreads();
+}
+
 constexpr int SORT_T = 1024;
 constexpr int SORT_WAVES = SORT_T / 64;
 constexpr int RDX_CAP = 8192;                    // packed 64-bit keys a bucket may hold in LDS
@@ -340,7 +407,7 @@ __global__ void __launch_bounds__(SORT_T, 8) bucket_sort_kernel(FastArgs a) {   
         //  and a 8192-counter scan each -- against ~1 us per ten steps of this network.)
         int P = 1;
         while (P < count) P <<= 1;
-        if (P > 1 && !(a.ablate & 1)) bitonic_sort<true, uint64_t>(kb0, count, P, t, SORT_T); else __syncthreads();
+        if (P > 1 && !(a.ablate & 1)) bitonic_sort_u64(kb0, count, P, t, SORT_T); else __syncthreads();
         const uint64_t* sorted = kb0;
         for (int i = t; i + 1 < count; i += SORT_T)
             if ((sorted[i] >> RDX_IDX_BITS) == (sorted[i + 1] >> RDX_IDX_BITS)) dup = 1;

@@ -335,6 +335,223 @@ __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ lane-pair variant on 16-bit keys
+// compare_sample_sets only ever sees 3-decimal PS values, float32(k / 1000) for k = 0..1000 (see the
+// counting kernel below), so a value IS its integer k.  Same two-lanes-per-row scheme as above, but
+//   * the staged tile holds 16-bit keys (0xFFFF = NaN): half the LDS per wave, twice the resident waves
+//     for the latency-bound merge;
+//   * a lane sorts its group as 2 x P/2 keys packed two per VGPR -- element i in the low half of
+//     register i mod P/2, element i + P/2 in the high half -- with v_pk_min_u16 / v_pk_max_u16: one
+//     instruction pair exchanges two comparators, half the instructions of the float network (only
+//     the flip of the last merge crosses the halves and costs six instructions per register pair);
+//   * floats come back through the table T[k] = float32(k / 1000): the numpy pairwise sum runs over
+//     T[key] in original order, medians are T[key] of the middle keys.
+// A row holding any value that is not exactly T[k] is marked RS_REDO and left to ranksum_wave_kernel.
+constexpr unsigned char RS_REDO_Q = 0xFF;       // (same mark as RS_REDO below)
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
+    union { uint32_t u; v2u16 v; } x, y, r;
+    x.u = a; y.u = b;
+    r.v = __builtin_elementwise_min(x.v, y.v);
+    return r.u;
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b) {
+    union { uint32_t u; v2u16 v; } x, y, r;
+    x.u = a; y.u = b;
+    r.v = __builtin_elementwise_max(x.v, y.v);
+    return r.u;
+}
+__device__ __forceinline__ uint32_t swap16(uint32_t a) { return (a >> 16) | (a << 16); }
+__device__ __forceinline__ uint32_t lo_hi(uint32_t lo_from, uint32_t hi_from) { return (lo_from & 0xffffu) | (hi_from & 0xffff0000u); }
+
+// ascending sort of P 16-bit keys, k[r] = element r | element (r + P/2) << 16  (flip + disperse network)
+template <int P>
+__device__ __forceinline__ void sort_keys16(uint32_t (&k)[P / 2]) {
+    constexpr int NR = P / 2;
+#pragma unroll
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        if (kk <= NR) {
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+                const int b = a ^ (kk - 1);
+                if (b > a) { const uint32_t mn = pk_min16(k[a], k[b]), mx = pk_max16(k[a], k[b]); k[a] = mn; k[b] = mx; }
+            }
+        } else {
+            // flip(P): element i <-> P-1-i, i.e. (k[a].lo, k[b].hi) and (k[b].lo, k[a].hi) with b = NR-1-a
+#pragma unroll
+            for (int a = 0; a < NR / 2; ++a) {
+                const int b = NR - 1 - a;
+                const uint32_t bs = swap16(k[b]);
+                const uint32_t mn = pk_min16(k[a], bs), mx = pk_max16(k[a], bs);
+                k[a] = lo_hi(mn, mx);
+                k[b] = swap16(lo_hi(mx, mn));
+            }
+        }
+#pragma unroll
+        for (int j = kk >> 2; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+                if ((a & j) == 0) { const uint32_t mn = pk_min16(k[a], k[a + j]), mx = pk_max16(k[a], k[a + j]); k[a] = mn; k[a + j] = mx; }
+            }
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) ranksum_pairq_kernel(const float* __restrict__ ps, int64_t n, int s,
+                                                            const int32_t* __restrict__ gsel, int n1, int n2,
+                                                            int stride /* u16 units, odd multiple ... */, RsOut o) {
+    extern __shared__ float smemq[];
+    constexpr int NR = P / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int nsel = n1 + n2;
+    float* T = smemq;                                                   // [1008] float32(k / 1000)
+    int* selL = reinterpret_cast<int*>(smemq + 1008);                   // [nsel]
+    unsigned short* tile = reinterpret_cast<unsigned short*>(selL + ((nsel + 1) & ~1)) + (size_t)wave * 32 * stride;
+    for (int k = threadIdx.x; k < 1008; k += blockDim.x) T[k] = (float)((double)k / 1000.0);
+    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    __syncthreads();
+    const int64_t n_groups = (n + 31) >> 5;
+    for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
+         g += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t row0 = g << 5;
+        unsigned redo_rows = 0;                        // bit r: row r holds a value that is not a 3-decimal PS
+        {   // stage 32 rows x nsel selected columns as keys (lane l owns selected columns l and l + 64)
+            const int rows_avail = (int)min((int64_t)32, n - row0);
+            const float* gbase = ps + row0 * s;
+            const bool act0 = lane < nsel, act1 = lane + 64 < nsel;
+            const int sel0 = act0 ? selL[lane] : 0;
+            const int sel1 = act1 ? selL[lane + 64] : 0;
+            constexpr int RB = 16;
+            for (int r0 = 0; r0 < 32; r0 += RB) {
+                float x0[RB], x1[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int rc = min(r0 + q, rows_avail - 1);
+                    x0[q] = act0 ? gbase[rc * s + sel0] : 0.f;
+                    x1[q] = act1 ? gbase[rc * s + sel1] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = r0 + q;
+                    const bool live = r < rows_avail;
+                    // key of a value: k = rint(1000 x) when x == T[k] exactly, 0xFFFF for NaN (and rows past the end)
+                    const float a0 = x0[q], a1 = x1[q];
+                    const int k0 = min(max((int)__builtin_rintf(a0 * 1000.0f), 0), 1000);
+                    const int k1 = min(max((int)__builtin_rintf(a1 * 1000.0f), 0), 1000);
+                    const bool nan0 = !(a0 == a0) || !live, nan1 = !(a1 == a1) || !live;
+                    const bool bad0 = act0 && !nan0 && T[k0] != a0, bad1 = act1 && !nan1 && T[k1] != a1;
+                    if (__ballot(bad0 || bad1)) redo_rows |= 1u << r;
+                    if (act0) tile[r * stride + lane] = nan0 ? (unsigned short)0xFFFF : (unsigned short)k0;
+                    if (act1) tile[r * stride + lane + 64] = nan1 ? (unsigned short)0xFFFF : (unsigned short)k1;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane >> 1, grp = lane & 1;
+        unsigned short* row = tile + r * stride;
+        unsigned short* grow = row + (grp ? n1 : 0);
+        const int cnt = grp ? n2 : n1;
+        // ---- compaction (NaNs dropped, order kept) through LDS, then the keys of this group in registers
+        int nv = 0;
+#pragma unroll
+        for (int e0 = 0; e0 < P; e0 += 16) {       // 16 reads in flight, then their compacting stores (all to indices <= e)
+            unsigned short v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = e0 + e < cnt ? grow[e0 + e] : (unsigned short)0xFFFF;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (v[e] != 0xFFFF) { grow[nv] = v[e]; ++nv; }
+        }
+        uint32_t key[NR];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            const uint32_t lo = a < nv ? grow[a] : 0xFFFFu, hi = a + NR < nv ? grow[a + NR] : 0xFFFFu;
+            key[a] = lo | (hi << 16);
+        }
+        // ---- numpy pairwise_sum over T[key] in original order (n <= 128 -> single block), npy loops_utils.h.src
+        float mean;
+        {
+            auto val = [&](int e) -> float { return T[e < NR ? (key[e] & 0xffffu) : (key[e - NR] >> 16)]; };   // (only read for e < nv)
+            float res;
+            if (nv < 8) {
+                res = 0.f;
+#pragma unroll
+                for (int e = 0; e < 7; ++e)
+                    if (e < nv) res += val(e);
+            } else {
+                float rr8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr8[j] = val(j);
+                const int main_n = nv - (nv & 7);
+#pragma unroll
+                for (int e = 8; e < P; ++e)
+                    if (e < main_n) rr8[e & 7] += val(e);
+                res = ((rr8[0] + rr8[1]) + (rr8[2] + rr8[3])) + ((rr8[4] + rr8[5]) + (rr8[6] + rr8[7]));
+#pragma unroll
+                for (int e = 8; e < P; ++e)
+                    if (e >= main_n && e < nv) res += val(e);
+            }
+            mean = nv > 0 ? res / (float)nv : 0.f;
+        }
+        sort_keys16<P>(key);
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            if (a < cnt) grow[a] = (unsigned short)(key[a] & 0xffffu);
+            if (a + NR < cnt) grow[a + NR] = (unsigned short)(key[a] >> 16);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();          // the partner's sorted group is in LDS
+        const int nv_other = __shfl_xor(nv, 1);
+        const int nv1 = grp ? nv_other : nv, nv2 = grp ? nv : nv_other;
+        const bool tested = nv1 >= 3 && nv2 >= 3;
+        const unsigned short* A = row;
+        const unsigned short* B = row + n1;
+        float med = 0.f;
+        int part = 0;
+        if (tested) {
+            const unsigned short* G = grp ? B : A;
+            const int h = nv >> 1;
+            med = (nv & 1) ? T[G[h]] : (T[G[h - 1]] + T[G[h]]) / 2.0f;      // np.median on float32
+            int i = 0, j = 0;
+            unsigned av = A[0], bv = B[0];
+            const int steps = nv1 + nv2;
+            for (int t = 0; t < steps; ++t) {
+                const bool before = grp ? (bv < av) : (bv <= av);
+                const bool take_b = j < nv2 && (i >= nv1 || before);
+                if (take_b) {
+                    ++j;
+                    bv = B[j < nv2 ? j : nv2 - 1];
+                } else {
+                    part += j;
+                    ++i;
+                    av = A[i < nv1 ? i : nv1 - 1];
+                }
+            }
+        }
+        const int u2 = part + __shfl_xor(part, 1);
+        const float med_other = __shfl_xor(med, 1);
+        const float mean_other = __shfl_xor(mean, 1);
+        const int64_t rr = row0 + r;
+        if (grp == 0 && rr < n) {
+            const bool redo = (redo_rows >> r) & 1u;
+            const unsigned long long packed =
+                (tested && !redo) ? ((unsigned long long)(unsigned)u2 | ((unsigned long long)nv1 << 32) | ((unsigned long long)nv2 << 48))
+                                  : 0ull;
+            o.tested[rr] = redo ? RS_REDO_Q : (tested ? 1 : 0);
+            reinterpret_cast<unsigned long long*>(o.p)[rr] = packed;
+            o.med1[rr] = med; o.med2[rr] = med_other;
+            o.mean1[rr] = tested ? mean : 0.f; o.mean2[rr] = tested ? mean_other : 0.f;
+            o.delta[rr] = med - med_other;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------ block-per-row variant
 constexpr int RB_THREADS = 256;
 
@@ -1028,6 +1245,37 @@ int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     return SDICE_OK;
 }
 
+// 16-bit-key lane-pair kernel, then the sorting wave kernel over the rows it marked (non 3-decimal values)
+template <int P>
+int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, const int32_t* g1, int n1,
+                 const int32_t* g2, int n2, RsOut o) {
+    const int stride = (n1 + n2) | 1;                      // u16 units
+    const int waves = 4;
+    const int nsel = n1 + n2;
+    const size_t lds = (size_t)1008 * 4 + (size_t)((nsel + 1) & ~1) * 4 + (size_t)waves * 32 * stride * 2;
+    int64_t blocks = sd_ceil_div(sd_ceil_div(n, 32), waves);
+    const int64_t cap = (int64_t)ctx->n_cu * 16;
+    if (blocks > cap) blocks = cap;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_pairq_kernel<P>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ranksum_pair_kernel", (ranksum_pairq_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
+              s, gsel, n1, n2, stride, o);
+    {   // rows marked RS_REDO (a value that is not float32(k/1000)): the float sorting kernel, marked rows only
+        const int ww = 4;
+        const size_t lds_w = (size_t)ww * (2 * 64 + 40) * 4;
+        const int64_t slots = (int64_t)ctx->n_cu * 32;
+        int ch = 64;
+        while (ch > 1 && sd_ceil_div(n, ch) < 2 * slots) ch >>= 1;
+        int64_t wb = sd_ceil_div(sd_ceil_div(n, ch), ww);
+        if (wb > (int64_t)ctx->n_cu * 8) wb = (int64_t)ctx->n_cu * 8;
+        SD_LAUNCH(ctx, "ranksum_wave_kernel", (ranksum_wave_kernel<1>), dim3((unsigned)wb), dim3(ww * 64), lds_w, d_ps, n, s, g1,
+                  n1, g2, n2, ch, 1, o);
+    }
+    SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
+              o.p, o.z);
+    return SDICE_OK;
+}
+
 }  // namespace
 
 extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const float* d_ps, const int32_t* d_g1,
@@ -1061,7 +1309,11 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         SD_HIP(hipMemcpyAsync(gsel, d_g1, (size_t)n1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         SD_HIP(hipMemcpyAsync(gsel + n1, d_g2, (size_t)n2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         const int big = n1 > n2 ? n1 : n2;
-        if (variant != 1) {      // auto: the lane-pair kernel (1.45x the lane kernel at 50 v 50, never slower)
+        if (variant == 0 && big > 16) {     // auto, groups of 17..64: the lane-pair kernel on 16-bit keys
+            if (big <= 32) return launch_pairq<32>(ctx, d_ps, n, s, gsel, d_g1, n1, d_g2, n2, o);
+            return launch_pairq<64>(ctx, d_ps, n, s, gsel, d_g1, n1, d_g2, n2, o);
+        }
+        if (variant != 1) {      // groups <= 16 and variant 4: the float lane-pair kernel (1.45x the lane kernel at 50 v 50)
             switch (next_pow2(big < 8 ? 8 : big)) {
                 case 8: return launch_pair<8>(ctx, d_ps, n, s, gsel, n1, n2, o);
                 case 16: return launch_pair<16>(ctx, d_ps, n, s, gsel, n1, n2, o);
