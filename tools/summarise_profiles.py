@@ -10,7 +10,7 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
-for wl in ("quant", "compare", "pairwise", "e2e"):
+for wl in ("quant", "compare", "pairwise", "e2e", "quant2m500"):
     files = glob.glob(os.path.join(src, f"{wl}_trace", "*", "*_kernel_stats.csv"))
     if not files:
         continue
@@ -29,7 +29,7 @@ for wl in ("quant", "compare", "pairwise", "e2e"):
 # HBM traffic of every kernel from the two PMC passes.  MI355X_MICROARCH.md (HBM section): both
 # counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream
 # (x2), WRITE_SIZE is exact.
-DOMINANT = {"quant": ("ps_tile_kernel", 1000000, 100), "compare": ("ranksum_pair_kernel", 1000000, 100),
+DOMINANT = {"quant": ("ps_tile_kernel", 1000000, 100), "compare": ("ranksum_pair", 1000000, 100),
             "pairwise": ("fisher_pairs_kernel", 25000, 200)}
 records = []
 for wl, (dom, n, s) in DOMINANT.items():
@@ -54,9 +54,29 @@ for wl, (dom, n, s) in DOMINANT.items():
             out.writerow([k, f"{f:.1f}", f"{w:.1f}", f"{(2 * f + w) * 1024:.0f}"])
     hit = [v for k, v in traffic.items() if k.startswith(dom)]
     if hit:
-        records.append({"workload": wl, "n": n, "s": s, "kernel": dom,
+        records.append({"workload": wl, "n": n, "s": s, "kernel": [k for k in traffic if k.startswith(dom)][0],
                         "hbm_bytes_per_launch": (2 * hit[0].get("FETCH_SIZE", 0) + hit[0].get("WRITE_SIZE", 0)) * 1024,
                         "source": f"profiles/{tag}_{wl}_pmc.csv (FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE)"})
 if records:
     json.dump(records, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+# SQ counters of the quant chain (one pass per counter), per kernel and launch
+sq = collections.defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(src, "quant_sq_*"))):
+    cname = os.path.basename(d)[len("quant_sq_"):]
+    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] == cname:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        sq[k][cname] = sum(v) / len(v)
+if sq:
+    names = sorted({c for v in sq.values() for c in v})
+    with open(os.path.join(dst, f"{tag}_quant_sq_counters.csv"), "w", newline="") as fh:
+        out = csv.writer(fh)
+        out.writerow(["kernel"] + [f"{c}_per_launch" for c in names])
+        for k in sorted(sq):
+            out.writerow([k] + [f"{sq[k].get(c, float('nan')):.0f}" for c in names])
 print("profiles written:", sorted(os.listdir(dst)))
