@@ -492,7 +492,7 @@ struct NbCfg {
     static constexpr int W = T + HB + HF;
     static constexpr int STAGE = 12 * T;       // list entries staged in LDS per tile
     static constexpr int KMAX = 16;            // entries a row keeps from its (single) walk, as 16-bit row distances
-    static constexpr int WIN_WORDS = 7 * W;    // cL (64 bit), R2, prefix max strand 0 / 1 (64 bit each)
+    static constexpr int WIN_WORDS = 6 * W;    // cL, running maximum (64 bit each), right, window index + position (16 bit each)
     static constexpr int UNION_WORDS = WIN_WORDS > STAGE ? WIN_WORDS : STAGE;
 };
 
@@ -523,13 +523,16 @@ template <int T>
 __global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a) {      // three workgroups per CU
     typedef NbCfg<T> Cfg;
     constexpr int W = Cfg::W, KMAX = Cfg::KMAX;
-    constexpr int EPT = (W + T - 1) / T;       // window elements per thread in the prefix-maximum scan
-    // the window, later the list stage:
-    //   cL[i]  = (chrom - chrom[window start]) << 32 | left      forward walks end at cL > (c << 32 | right)
-    //   wR[i]  = right << 1 | strand
-    //   pm0/1  = running maximum over the window rows <= i of strand 0 / 1 of  (chrom - ...) << 32 | right:
-    //            a backward walk for (c, left) ends at the first row with pm < (c << 32 | left) -- nothing
-    //            at or before it (of this chromosome and strand) reaches `left`
+    constexpr int EPT = (W + T - 1) / T;       // window rows per thread while the window is built
+    // The window [wlo, whi) is held COMPACTED BY STRAND, so that a walk only ever visits rows of its own
+    // strand (half the visits of a walk over the interleaved rows): the '+' rows fill the arrays from the
+    // front in row order, the '-' rows from the back in reverse order, position k holds
+    //   cL[k]  = (chrom - chrom[window start]) << 32 | left      forward walks end at cL > (c << 32 | right)
+    //   pm[k]  = running maximum over the window rows of this strand up to this one of (chrom - ..) << 32 | right:
+    //            a backward walk for (c, left) ends at the first row with pm < (c << 32 | left) -- nothing at
+    //            or before it (of this chromosome and strand) reaches `left`
+    //   wR[k]  = right,  rid[k] = window index of the row,  pos[i] = position of window row i.
+    // The same LDS is the list stage afterwards.
     __shared__ __align__(16) uint32_t u_mem[Cfg::UNION_WORDS];
     __shared__ int16_t tmp[(KMAX + 1) * T];     // (row KMAX is a dummy target for non-hits)
     __shared__ uint32_t wsum[T / 64];
@@ -537,9 +540,10 @@ __global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a
     __shared__ uint32_t s_misc[4];             // [1] maxlen, [2] reach
     __shared__ unsigned long long s_base;
     unsigned long long* cL = reinterpret_cast<unsigned long long*>(u_mem);
-    unsigned long long* pm0 = cL + W;
-    unsigned long long* pm1 = pm0 + W;
-    uint32_t* wR = reinterpret_cast<uint32_t*>(pm1 + W);
+    unsigned long long* pm = cL + W;
+    uint32_t* wR = reinterpret_cast<uint32_t*>(pm + W);
+    uint16_t* rid = reinterpret_cast<uint16_t*>(wR + W);
+    uint16_t* pos = rid + W;
     int32_t* stage = reinterpret_cast<int32_t*>(u_mem);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int n = (int)a.n;
@@ -564,56 +568,79 @@ __global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a
     const int wn = whi - wlo;
     const uint32_t c0w = a.rowC[wlo];
     const uint32_t l0w = a.rowL[wlo];
-    for (int i = t; i < wn; i += T) {
-        cL[i] = ((unsigned long long)(a.rowC[wlo + i] - c0w) << 32) | a.rowL[wlo + i];
-        wR[i] = a.rowR2[wlo + i];
-    }
-    __syncthreads();
-    const uint32_t maxlen = s_misc[1];
     const int64_t cap = a.col_cap;
+    int n1 = 0;                                // '-' rows in the window
     {
-        unsigned long long v0[EPT], v1[EPT], r0 = 0, r1 = 0;
+        // thread t builds window rows t*EPT .. (read straight from the row arrays): scan of the '-' count
+        // (position inside the strand) and of the two running maxima, then the compacted stores
+        unsigned long long comp[EPT], own_cl[EPT], r0 = 0, r1 = 0;
+        uint32_t rr[EPT], str[EPT], c1 = 0;
+        unsigned long long v0[EPT], v1[EPT];
+        uint32_t cb[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = t * EPT + e;
+            comp[e] = 0; own_cl[e] = 0; rr[e] = 0; str[e] = 0;
+            cb[e] = c1;
             if (i < wn) {
-                const uint32_t r2 = wR[i];
-                const unsigned long long comp = (cL[i] & 0xffffffff00000000ull) | (r2 >> 1);
-                if (r2 & 1u) r1 = comp > r1 ? comp : r1; else r0 = comp > r0 ? comp : r0;
+                const uint32_t rc = a.rowC[wlo + i] - c0w, r2 = a.rowR2[wlo + i];
+                own_cl[e] = ((unsigned long long)rc << 32) | a.rowL[wlo + i];
+                rr[e] = r2 >> 1; str[e] = r2 & 1u;
+                comp[e] = ((unsigned long long)rc << 32) | rr[e];
+                if (str[e]) { r1 = comp[e] > r1 ? comp[e] : r1; ++c1; } else { r0 = comp[e] > r0 ? comp[e] : r0; }
             }
             v0[e] = r0; v1[e] = r1;
         }
         unsigned long long x0 = r0, x1 = r1;
+        uint32_t xc = c1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned long long y0 = __shfl_up(x0, o), y1 = __shfl_up(x1, o);
-            if (lane >= o) { x0 = y0 > x0 ? y0 : x0; x1 = y1 > x1 ? y1 : x1; }
+            const uint32_t yc = __shfl_up(xc, o);
+            if (lane >= o) { x0 = y0 > x0 ? y0 : x0; x1 = y1 > x1 ? y1 : x1; xc += yc; }
         }
-        if (lane == 63) { wmax0[w] = x0; wmax1[w] = x1; }
+        if (lane == 63) { wmax0[w] = x0; wmax1[w] = x1; wsum[w] = xc; }
         __syncthreads();
         unsigned long long p0 = __shfl_up(x0, 1), p1 = __shfl_up(x1, 1);      // exclusive over the threads before
+        uint32_t pc = xc - c1;
         if (lane == 0) { p0 = 0; p1 = 0; }
-        for (int k = 0; k < w; ++k) { p0 = wmax0[k] > p0 ? wmax0[k] : p0; p1 = wmax1[k] > p1 ? wmax1[k] : p1; }
+#pragma unroll
+        for (int k = 0; k < T / 64; ++k) {
+            if (k < w) { p0 = wmax0[k] > p0 ? wmax0[k] : p0; p1 = wmax1[k] > p1 ? wmax1[k] : p1; pc += wsum[k]; }
+            n1 += (int)wsum[k];
+        }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = t * EPT + e;
-            if (i < wn) { pm0[i] = v0[e] > p0 ? v0[e] : p0; pm1[i] = v1[e] > p1 ? v1[e] : p1; }
+            if (i < wn) {
+                const int before1 = (int)(pc + cb[e]);             // '-' rows before window row i
+                const int k = str[e] ? W - 1 - before1 : i - before1;
+                const unsigned long long m = str[e] ? (v1[e] > p1 ? v1[e] : p1) : (v0[e] > p0 ? v0[e] : p0);
+                cL[k] = own_cl[e]; pm[k] = m; wR[k] = rr[e]; rid[k] = (uint16_t)i; pos[i] = (uint16_t)k;
+            }
         }
     }
-    __syncthreads();
+    __syncthreads();                           // (wsum is reused by the degree scan below: all reads above are done)
+    const uint32_t maxlen = s_misc[1];
+    const int n0 = wn - n1;                    // '+' rows occupy [0, n0), '-' rows [W - n1, W)
 
     const int r = t0 + t;
     const int ri = r - wlo;
     const bool act = t < nr;
+    int p = 0;
     unsigned long long own = 0;
-    uint32_t r2 = 0;
-    if (act) { own = cL[ri]; r2 = wR[ri]; }
+    uint32_t rgt = 0;
+    if (act) { p = pos[ri]; own = cL[p]; rgt = wR[p]; }
+    const uint32_t st = p >= W - n1 ? 1u : 0u;
     const uint32_t l = (uint32_t)own, crel = (uint32_t)(own >> 32), c = crel + c0w;
-    const uint32_t rgt = r2 >> 1, st = r2 & 1u;
     const unsigned long long tb = own;                                          // (chrom, left)
     const unsigned long long tf = (own & 0xffffffff00000000ull) | rgt;          // (chrom, right)
     // the window maxima decide the end of the backward walk iff no row before the window can reach `left`
     const bool exact = wlo == 0 || crel != 0 || l0w + maxlen < l;
+    // strand-local direction of increasing row number, and the bounds of this strand's region
+    const int dfw = st ? -1 : 1;
+    const int first = st ? W - 1 : 0;                      // position of the strand's first window row
+    const int last = st ? W - n1 : n0 - 1;                 // ... and of its last one
 
     uint32_t deg = 0;
     int far_b = r, far_f = r;
@@ -628,57 +655,54 @@ __global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a
         if (d < 0) far_b = q; else far_f = q;
     };
     if (act && !(a.ablate & 64)) {
-        // ---- earlier rows, most recent first.  The loops are written without conditional statements
-        //      (loads at a clamped index, a dummy 17th list row for the non-hits, two rows per trip):
-        //      as nested ifs they compiled to two serialised LDS round trips and ~25 exec-mask
-        //      instructions per row.
+        // The loops are written without conditional statements (loads at a clamped position, a dummy 17th
+        // list row for the non-hits, two rows per trip): as nested ifs they compiled to two serialised LDS
+        // round trips and ~25 exec-mask instructions per row.
         int16_t* mytmp = tmp + t;
-        auto take = [&](bool hit, int d, int q) {
+        auto take = [&](bool hit, int wi) {
             const uint32_t slot = (hit & (deg < (uint32_t)KMAX)) ? deg : (uint32_t)KMAX;
-            mytmp[slot * T] = (int16_t)d;
+            mytmp[slot * T] = (int16_t)(wi - ri);
             deg += hit ? 1u : 0u;
-            return hit ? q : -1;
+            return hit ? wlo + wi : -1;
         };
+        // in strand-local coordinates u = (position - first) * dfw  (0 = the strand's first window row)
+        const int up = (p - first) * dfw, ulast = (last - first) * dfw;
+        // ---- earlier rows of this strand, most recent first
         if (exact) {
-            const unsigned long long* pm = st ? pm1 : pm0;
-            int qi = ri - 1;
+            int u = up - 1;
             for (;;) {
-                const int q0 = max(qi, 0), q1 = max(qi - 1, 0);
+                const int q0 = first + dfw * max(u, 0), q1 = first + dfw * max(u - 1, 0);
                 const unsigned long long m0 = pm[q0], m1 = pm[q1];
                 const uint32_t x0 = wR[q0], x1 = wR[q1];
-                if (!((qi >= 0) & (m0 >= tb))) break;
-                // (pm >= target: row qi is of this chromosome)
-                const int f0 = take(((x0 & 1u) == st) & ((x0 >> 1) >= l), qi - ri, wlo + qi);
+                const int i0 = rid[q0], i1 = rid[q1];
+                if (!((u >= 0) & (m0 >= tb))) break;
+                const int f0 = take(x0 >= l, i0);              // (pm >= target: the row is of this chromosome)
                 far_b = f0 >= 0 ? f0 : far_b;
-                --qi;
-                if (!((qi >= 0) & (m1 >= tb))) break;
-                const int f1 = take(((x1 & 1u) == st) & ((x1 >> 1) >= l), qi - ri, wlo + qi);
+                --u;
+                if (!((u >= 0) & (m1 >= tb))) break;
+                const int f1 = take(x1 >= l, i1);
                 far_b = f1 >= 0 ? f1 : far_b;
-                --qi;
+                --u;
             }
-            if (qi < 0 && wlo > 0) walk_back_global(a, wlo - 1, c, l, st, maxlen, emit_far);
+            if (u < 0 && wlo > 0) walk_back_global(a, wlo - 1, c, l, st, maxlen, emit_far);
         } else {
             walk_back_global(a, r - 1, c, l, st, maxlen, emit_far);
         }
-        // ---- later rows in order
+        // ---- later rows of this strand in order: every row up to the first with (chrom, left) > (c, right)
         {
-            int qi = ri + 1;
-            const int last = wn - 1;
+            int u = up + 1;
             for (;;) {
-                const int q0 = min(qi, last), q1 = min(qi + 1, last);
+                const int q0 = first + dfw * min(u, ulast), q1 = first + dfw * min(u + 1, ulast);
                 const unsigned long long c0 = cL[q0], c1 = cL[q1];
-                const uint32_t x0 = wR[q0], x1 = wR[q1];
-                if (!((qi <= last) & (c0 <= tf))) break;
-                // (cL <= target behind row r: same chromosome)
-                const int f0 = take((x0 & 1u) == st, qi - ri, wlo + qi);
-                far_f = f0 >= 0 ? f0 : far_f;
-                ++qi;
-                if (!((qi <= last) & (c1 <= tf))) break;
-                const int f1 = take((x1 & 1u) == st, qi - ri, wlo + qi);
-                far_f = f1 >= 0 ? f1 : far_f;
-                ++qi;
+                const int i0 = rid[q0], i1 = rid[q1];
+                if (!((u <= ulast) & (c0 <= tf))) break;
+                far_f = take(true, i0);
+                ++u;
+                if (!((u <= ulast) & (c1 <= tf))) break;
+                far_f = take(true, i1);
+                ++u;
             }
-            if (qi > last && whi < n) walk_fwd_global(a, whi, n, c, rgt, st, emit_far);
+            if (u > ulast && whi < n) walk_fwd_global(a, whi, n, c, rgt, st, emit_far);
         }
         if (deg > (uint32_t)KMAX) redo = true;
     }
@@ -909,8 +933,8 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     }
     {
         const size_t lds = (size_t)a.B * 16;
-        // tiles of 2048 keys (512 threads) up to 1 M keys keep >= 2 workgroups per CU busy; 4096 beyond
-        if (n <= (1 << 21)) {
+        // tiles of 2048 keys (512 threads) for small inputs, 4096 (1024 threads) beyond
+        if (n <= (1 << 19)) {      // (4096-key tiles halve the global atomics: 27.5 -> 21.4 us at 1 M keys)
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter_kernel<512>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SD_LAUNCH(ctx, "bucket_scatter_kernel", (bucket_scatter_kernel<512>), dim3(grid_for(n, 512 * SC_KPT)), dim3(512), lds, a);

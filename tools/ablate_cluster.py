@@ -15,6 +15,8 @@ d = [ctx.to_device(x) for x in junc]
 d_row_of, d_rp = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
 ctx.cluster_dev(*d, d_row_of, d_rp)
 for m in masks:
+    ctx.set_param("cluster.big_tiles", 1 if m < 0 else 0)
+    m = abs(m) if m != -9999 else 0
     ctx.set_param("cluster.ablate", m)
     ctx.prof_enable(0)
     for _ in range(3):

@@ -44,6 +44,16 @@ __global__ void k_barrier(uint32_t* out, int iters) {
     if (s[threadIdx.x] == 0xffffffffu) out[0] = 1;
 }
 
+__global__ void k_fma64(double* out, int iters) {      // 8 independent f64 FMA chains per lane: the f64 VALU issue rate
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 1.0000001, c = 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+        a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+    }
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) out[0] = a0;
+}
+
 template <typename F> float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -63,6 +73,12 @@ int main() {
             printf("wgs %4d threads %4d : valu32 %.2f ns/iter(5 ops)  valu64 %.2f ns/iter  lds chain %.1f ns/hop  lds rw step %.1f ns  barrier+lds %.1f ns\n",
                    wgs, th, a * 1e6 / it, b * 1e6 / it, c * 1e6 / it, e * 1e6 / it, g * 1e6 / it);
         }
+    }
+    {
+        const int it64 = 1 << 14;
+        float ms = timeit([&] { k_fma64<<<2048, 1024>>>((double*)d, it64); });
+        const double fmas = 2048.0 * 1024 * 8 * it64;
+        printf("f64 FMA rate: %.2f T FMA lane-ops/s (= %.1f TFLOP/s), %.3f ms\n", fmas / (ms * 1e-3) / 1e12, 2 * fmas / (ms * 1e-3) / 1e12, ms);
     }
     return 0;
 }
