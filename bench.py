@@ -104,6 +104,15 @@ class Dist:
         self.pg.all_reduce(t, op=self.pg.ReduceOp.SUM)
         return float(t[0])
 
+    def all_ok(self, ok):
+        """True iff `ok` holds on every rank (keeps the ranks in step when one of them failed a step)"""
+        if not self.pg:
+            return bool(ok)
+        import torch
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MIN)
+        return bool(t[0] > 0.5)
+
     def max(self, x):
         if not self.pg:
             return x
@@ -254,21 +263,35 @@ class StrongQuantWorkload(QuantWorkload):
 
     def ps_allgather(self, dist, reps=3):
         """the collective BASELINE.json's north_star names -- all-gather of the PS shards over xGMI --
-        timed beside the design that leaves every shard in its owner's HBM"""
+        timed beside the design that leaves every shard in its owner's HBM.  Every rank goes through the
+        same sequence of control-plane calls whatever fails where (a rank that raised must not leave the
+        others waiting in a barrier)."""
         from splicedice_amd import distributed
-        comm = distributed.RcclComm(self.ctx, dist.rank, self.world, dist.bcast_bytes)
+        err, comm = None, None
+        try:
+            comm = distributed.RcclComm(self.ctx, dist.rank, self.world, dist.bcast_bytes)
+        except Exception as e:
+            err = f"communicator: {str(e)[:240]}"
+        if not dist.all_ok(err is None):
+            return {"ok": False, "error": err or "communicator failed on another rank"}
         max_rows = max(b[3] - b[2] for b in self.ranges)
-        out = distributed.gather_ps_dev(self.ctx, comm, self.d_ps, self.n, self.s, max_rows)
-        self.ctx.sync()
-        dist.barrier()
-        self.ctx.timer_start()
-        for _ in range(reps):
+        ms, ok = float("nan"), False
+        try:
             out = distributed.gather_ps_dev(self.ctx, comm, self.d_ps, self.n, self.s, max_rows)
-        ms = self.ctx.timer_stop() / reps
-        got = out.offset(dist.rank * max_rows * self.s, (min(self.n, 64), self.s)).to_host()
-        ok = bool(np.array_equal(got, self.d_ps.offset(0, (min(self.n, 64), self.s)).to_host(), equal_nan=True))
+            self.ctx.sync()
+            self.ctx.timer_start()
+            for _ in range(reps):
+                out = distributed.gather_ps_dev(self.ctx, comm, self.d_ps, self.n, self.s, max_rows)
+            ms = self.ctx.timer_stop() / reps
+            got = out.offset(dist.rank * max_rows * self.s, (min(self.n, 64), self.s)).to_host()
+            ok = bool(np.array_equal(got, self.d_ps.offset(0, (min(self.n, 64), self.s)).to_host(), equal_nan=True))
+        except Exception as e:
+            err = f"all-gather: {str(e)[:240]}"
+        if not dist.all_ok(err is None):
+            return {"ok": False, "error": err or "all-gather failed on another rank"}
         total = self.world * max_rows * self.s * 4
-        return {"ok": ok, "ms": round(dist.max(ms), 4), "bytes_gathered_per_rank": total, "rccl_ranks": self.world,
+        ms = dist.max(ms)
+        return {"ok": dist.all_ok(ok), "ms": round(ms, 4), "bytes_gathered_per_rank": total, "rccl_ranks": self.world,
                 "GB_per_s_per_rank": round(total * (self.world - 1) / self.world / (ms * 1e-3) / 1e9, 1)}
 
 
@@ -622,32 +645,46 @@ def main():
 
     ps_allgather = None
     if strong:
-        try:
-            ps_allgather = wl.ps_allgather(dist)
-        except Exception as e:      # reported, never hidden: the timed steps above contain no collective
-            ps_allgather = {"ok": False, "error": str(e)[:300]}
+        ps_allgather = wl.ps_allgather(dist)      # reported, never hidden: the timed steps above contain no collective
         dist.barrier()
 
     allgather = None
     if args.gpus > 1 and not strong and not getattr(wl, "needs_comm", False):
-        # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction)
+        # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction); every rank
+        # goes through the same control-plane calls whatever fails where
+        err = None
         try:
             uid = ctx.comm_unique_id() if dist.rank == 0 else None
-            uid = dist.bcast_bytes(uid, 128)
-            ctx.comm_init(uid, dist.rank, args.gpus)
-            send = ctx.to_device(np.full(wl.n, float(dist.rank)))
-            recv = ctx.empty(wl.n * args.gpus, np.float64)
-            ctx.allgather_dev(send, recv)
-            ctx.sync()
-            ctx.timer_start()
-            for _ in range(5):
+        except Exception as e:
+            uid, err = bytes(128), f"unique id: {str(e)[:200]}"
+        uid = dist.bcast_bytes(uid, 128)
+        try:
+            if err is None:
+                ctx.comm_init(uid, dist.rank, args.gpus)
+        except Exception as e:
+            err = f"comm_init: {str(e)[:240]}"
+        if not dist.all_ok(err is None):
+            allgather = {"ok": False, "error": err or "communicator failed on another rank"}
+        else:
+            ms, ok = float("nan"), False
+            try:
+                send = ctx.to_device(np.full(wl.n, float(dist.rank)))
+                recv = ctx.empty(wl.n * args.gpus, np.float64)
                 ctx.allgather_dev(send, recv)
-            ms = ctx.timer_stop() / 5
-            got = recv.to_host().reshape(args.gpus, wl.n)[:, 0]
-            allgather = {"ok": bool(np.array_equal(got, np.arange(args.gpus))), "bytes_per_rank": wl.n * 8,
-                         "ms": round(ms, 4), "rccl_ranks": args.gpus}
-        except Exception as e:  # reported, never hidden: the timed steps above contain no collective
-            allgather = {"ok": False, "error": str(e)[:300]}
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(5):
+                    ctx.allgather_dev(send, recv)
+                ms = ctx.timer_stop() / 5
+                got = recv.to_host().reshape(args.gpus, wl.n)[:, 0]
+                ok = bool(np.array_equal(got, np.arange(args.gpus)))
+            except Exception as e:
+                err = f"all-gather: {str(e)[:240]}"
+            if not dist.all_ok(err is None):
+                allgather = {"ok": False, "error": err or "all-gather failed on another rank"}
+            else:
+                allgather = {"ok": dist.all_ok(ok), "bytes_per_rank": wl.n * 8, "ms": round(dist.max(ms), 4),
+                             "rccl_ranks": args.gpus}
         dist.barrier()
 
     cpu = None

@@ -81,8 +81,19 @@ class RcclComm:
 
     def __init__(self, ctx, rank, world, bcast_bytes):
         self.ctx, self.rank, self.world = ctx, rank, world
-        uid = ctx.comm_unique_id() if rank == 0 else None
-        ctx.comm_init(bcast_bytes(uid, 128), rank, world)
+        # every rank takes part in the broadcast whatever happens on rank 0 (an all-zero id = "rank 0 failed")
+        uid, err = None, None
+        if rank == 0:
+            try:
+                uid = ctx.comm_unique_id()
+            except Exception as e:       # noqa: BLE001 -- re-raised below, after the broadcast
+                uid, err = bytes(128), e
+        uid = bcast_bytes(uid, 128)
+        if err is not None:
+            raise err
+        if not any(uid):
+            raise RuntimeError("RCCL unique id could not be created on rank 0")
+        ctx.comm_init(uid, rank, world)
 
     def allgather(self, x):
         if not _is_dev(x):
