@@ -3,7 +3,7 @@
 commands do not need pysam/statsmodels just to start.
 
 Sub-commands outside the accelerated path (bam_to_junc_bed, intron_coverage,
-ir_table, subset, select) are registered by name so that scripts get
+subset, select) are registered by name so that scripts get
 a clear message instead of an argparse "invalid choice".
 """
 import argparse
@@ -17,8 +17,9 @@ ACCELERATED = {
     "pairwise": "splicedice_amd.pairwise",
     "similarity": "splicedice_amd.similarity",
     "findOutliers": "splicedice_amd.find_outliers",
+    "ir_table": "splicedice_amd.ir_table",
 }
-NOT_BUILT = ["bam_to_junc_bed", "intron_coverage", "ir_table", "subset", "select"]
+NOT_BUILT = ["bam_to_junc_bed", "intron_coverage", "subset", "select"]
 
 
 def _not_built(name):

@@ -38,6 +38,13 @@
 // dependent PS launch) and the failure is reported then.
 #include "common.h"
 
+// Timing experiments (tools/ablate_cluster.py, param cluster.ablate) are compiled in only with
+// `make EXTRA=-DSDICE_CLUSTER_ABLATE=1`; the shipped kernels carry no trace of them.
+#ifndef SDICE_CLUSTER_ABLATE
+#define SDICE_CLUSTER_ABLATE 0
+#endif
+#define SD_ABL(a, bit) (SDICE_CLUSTER_ABLATE && ((a).ablate & (bit)))
+
 int sd_cluster_legacy(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* d_left, const int32_t* d_right,
                       const int8_t* d_strand, int32_t* d_row_of, int64_t* d_row_ptr, int64_t* nnz_out);
 
@@ -106,7 +113,7 @@ __global__ void __launch_bounds__(256) sample_rank_kernel(FastArgs a) {
     const int64_t split = i - j0;                       // j0 + q < i  <=>  q < split
     uint32_t cnt = 0;
 #pragma unroll 16
-    for (int q = 0; q < ((a.ablate & 8) ? 0 : 256); ++q) {
+    for (int q = 0; q < (SD_ABL(a, 8) ? 0 : 256); ++q) {
         const uint64_t k = jk[q];
         cnt += (k < ik || (k == ik && q < split)) ? 1u : 0u;
     }
@@ -172,7 +179,7 @@ __global__ void __launch_bounds__(T) bucket_scatter_kernel(FastArgs a) {
     __syncthreads();
     for (int b = t; b < B; b += T) {
         const uint32_t c = cnt[b];
-        base[b] = (c && !(a.ablate & 32)) ? atomicAdd(&a.cursor[b], c) : 0u;
+        base[b] = (c && !SD_ABL(a, 32)) ? atomicAdd(&a.cursor[b], c) : 0u;
     }
     if (t == 0) {
         uint32_t m = 0;
@@ -185,7 +192,7 @@ __global__ void __launch_bounds__(T) bucket_scatter_kernel(FastArgs a) {
         if (bk[q] == 0xffffffffu) continue;
         const int64_t i = tile0 + q * T + t;
         const uint64_t pos = (uint64_t)base[bk[q]] + lr[q];
-        if (a.ablate & 16) continue;
+        if (SD_ABL(a, 16)) continue;
         if (pos < (uint64_t)a.slot_cap) a.slots[(int64_t)bk[q] * a.slot_cap + (int64_t)pos] = make_uint4(kc[q], kl[q], kr[q], (uint32_t)i);
         else s_over = 1;
     }
@@ -407,11 +414,11 @@ __global__ void __launch_bounds__(SORT_T, 8) bucket_sort_kernel(FastArgs a) {   
         //  and a 8192-counter scan each -- against ~1 us per ten steps of this network.)
         int P = 1;
         while (P < count) P <<= 1;
-        if (P > 1 && !(a.ablate & 1)) bitonic_sort_u64(kb0, count, P, t, SORT_T); else __syncthreads();
+        if (P > 1 && !SD_ABL(a, 1)) bitonic_sort_u64(kb0, count, P, t, SORT_T); else __syncthreads();
         const uint64_t* sorted = kb0;
         for (int i = t; i + 1 < count; i += SORT_T)
             if ((sorted[i] >> RDX_IDX_BITS) == (sorted[i + 1] >> RDX_IDX_BITS)) dup = 1;
-        if (!(a.ablate & 2)) emit_all([&](int i) { return src[sorted[i] & ((1u << RDX_IDX_BITS) - 1u)]; });
+        if (!SD_ABL(a, 2)) emit_all([&](int i) { return src[sorted[i] & ((1u << RDX_IDX_BITS) - 1u)]; });
     } else {
         int P = 1;
         while (P < count) P <<= 1;
@@ -654,7 +661,7 @@ __global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a
         ++deg;
         if (d < 0) far_b = q; else far_f = q;
     };
-    if (act && !(a.ablate & 64)) {
+    if (act && !SD_ABL(a, 64)) {
         // The loops are written without conditional statements (loads at a clamped position, a dummy 17th
         // list row for the non-hits, two rows per trip): as nested ifs they compiled to two serialised LDS
         // round trips and ~25 exec-mask instructions per row.
@@ -721,7 +728,7 @@ __global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a
     for (int k = 0; k < T / 64; ++k) { const uint32_t v = wsum[k]; if (k < w) wbase += v; total += v; }
     const uint32_t loff = wbase + x - deg;
     if (w == 0) {
-        const unsigned long long base = (a.ablate & 128) ? 0ull : lookback_exclusive(a.tile_state, tile, (unsigned long long)total, lane, a.sb);
+        const unsigned long long base = SD_ABL(a, 128) ? 0ull : lookback_exclusive(a.tile_state, tile, (unsigned long long)total, lane, a.sb);
         if (lane == 0) {
             s_base = base;
             if (s_misc[2]) atomicMax(&a.sb[SB_REACH + (tile % SB_SLOTS)], (unsigned long long)s_misc[2]);

@@ -165,8 +165,10 @@ def test_dispatcher_names_and_flags():
     assert a.recluster and a.clusters is None
     a = p.parse_args(["findOutliers", "--psiSPLICEDICE", "m.npz", "-m", "man.tsv"])
     assert a.nullMan is None and a.outlierCutoff == 3 and a.dpsiThrsh == 0.1
-    for name in ("bam_to_junc_bed", "intron_coverage", "ir_table", "subset", "select"):
+    for name in ("bam_to_junc_bed", "intron_coverage", "subset", "select"):
         assert p.parse_args([name]).command == name
+    a = p.parse_args(["ir_table", "-i", "c.tsv", "-c", "k.tsv", "-d", "cov", "-o", "out", "-r"])
+    assert a.makeRSDtable and not a.allJunctions and not a.singleJunctionCalculation and a.RSDthreshold == 1.0
     a = p.parse_args(["similarity", "-c", "vs.tsv", "-a", "allps.tsv", "-o", "out.tsv"])
     assert a.manifest is None and a.comparison == "vs.tsv"
 
@@ -262,3 +264,53 @@ def test_strong_scaling_partition_helpers():
     a = synth.make_counts_rows(70000, 140001, 3, 5)
     b = synth.make_counts_rows(0, 140001, 3, 5)
     assert np.array_equal(a, b[70000:])
+
+
+# ----------------------------------------------------------------------------------- ir_table (host logic)
+class _SumEngine:
+    """host double of the one engine call ir_table makes (exclusion sums over a CSR)"""
+
+    def ps(self, counts, row_ptr, col, want_excl=False, want_ps=True):
+        from oracle import oracle_np as O
+        return O.calculate_psi_vectorised(counts, row_ptr, col)[1]
+
+
+def _ir_args(golden_dir, tmp_path, tag, **kw):
+    import argparse
+    d = os.path.join(golden_dir, "ir_table")
+    return argparse.Namespace(inclusionCounts=os.path.join(d, "in_inclusionCounts.tsv"), clusters=os.path.join(d, "in_allClusters.tsv"),
+                              coverageDirectory=os.path.join(d, "coverage"), outputPrefix=str(tmp_path / tag), makeRSDtable=True,
+                              annotation=os.path.join(d, "anno.gtf"), RSDthreshold=1.0, **kw)
+
+
+def _table_by_column(path):
+    with open(path) as fh:
+        rows = [line.rstrip("\n").split("\t") for line in fh]
+    return {(r[0], c): v for r in rows[1:] for c, v in zip(rows[0][1:], r[1:])}, [r[0] for r in rows[1:]], sorted(rows[0][1:])
+
+
+@pytest.mark.parametrize("tag,kw", [("annotated", dict(allJunctions=False, singleJunctionCalculation=False)),
+                                    ("all", dict(allJunctions=True, singleJunctionCalculation=False)),
+                                    ("all_single", dict(allJunctions=True, singleJunctionCalculation=True))])
+def test_ir_table_against_reference_goldens(golden_dir, tmp_path, tag, kw, capsys):
+    """tests/golden/ir_table was written by the reference's ir_table.py (make_golden_ir.py).  Sample columns
+    come in os.listdir order there and here, so cells are compared by (junction, sample); the message lines
+    ("mxCluster ...") must be the same multiset."""
+    from splicedice_amd import ir_table
+    ir_table.run_with(_ir_args(golden_dir, tmp_path, tag, **kw), ctx=_SumEngine())
+    said = [ln for ln in capsys.readouterr().out.splitlines() if not ln.startswith("Done")]
+    d = os.path.join(golden_dir, "ir_table")
+    with open(os.path.join(d, f"expected_{tag}_stdout.txt")) as fh:
+        assert sorted(said) == sorted(fh.read().splitlines())
+    for suffix in ("_intron_retention.tsv", "_intron_retention_RSD.tsv"):
+        got, got_rows, got_cols = _table_by_column(str(tmp_path / tag) + suffix)
+        want, want_rows, want_cols = _table_by_column(os.path.join(d, f"expected_{tag}{suffix}"))
+        assert got_rows == want_rows and got_cols == want_cols and got == want
+
+
+def test_ir_table_without_rsd_table_dies_like_the_reference(golden_dir, tmp_path):
+    from splicedice_amd import ir_table
+    a = _ir_args(golden_dir, tmp_path, "x", allJunctions=True, singleJunctionCalculation=False)
+    a.makeRSDtable = False
+    with pytest.raises(KeyError):          # RSD[sample][junction] is never filled without -r (ir_table.py:140-145)
+        ir_table.run_with(a, ctx=_SumEngine())

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel timing of the fast clustering chain under the cluster.ablate switches (tuning aid).
+"""Per-kernel timing of the fast clustering chain under the cluster.ablate switches (tuning aid; the switches
+exist only in a library built with `make -C splicedice_amd/csrc EXTRA=-DSDICE_CLUSTER_ABLATE=1`).
 Results are wrong under ablation; calls are asynchronous and their status is discarded."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
