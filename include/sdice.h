@@ -242,6 +242,13 @@ int sdice_rowstats(sdice_ctx* ctx, int64_t n, int32_t s, const void* data, int d
 int sdice_rowstats_dev(sdice_ctx* ctx, int64_t n, int32_t s, const void* d_data, int dtype, const int32_t* d_idx,
                        int32_t k, void* d_mean, void* d_std, int32_t* d_nan);
 
+/* ---- junction-axis shard plan (host only, no context): `world` contiguous row ranges cut at clean
+ *      positions (no overlap edge crosses the cut) nearest to k*n/world; where none lies within
+ *      max_shift_frac * n / world of it the ideal position is kept and the shard gets a read-only halo.
+ *      plan[world][4] = own_lo, own_hi (rows whose results the rank produces), ext_lo, ext_hi (rows it holds). */
+int sdice_shard_plan(int64_t n, const int64_t* row_ptr, const int32_t* col, int32_t world, double max_shift_frac,
+                     int64_t* plan);
+
 /* ---- multi-GPU (new; the reference is single-process): one context per rank,
  *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque
  *      bytes created on rank 0 and distributed by the caller (any channel). */

@@ -29,36 +29,20 @@ def clean_cuts(row_ptr, col):
 
 
 def shard_plan(row_ptr, col, world, max_shift_frac=0.02):
-    """-> list of dicts(own_lo, own_hi, ext_lo, ext_hi), one per rank.
+    """-> list of dicts(own_lo, own_hi, ext_lo, ext_hi), one per rank (sdice_shard_plan, host C++).
 
     own_*: rows whose results the rank produces; ext_*: rows it must hold (own + halo).
     """
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    col = np.asarray(col, dtype=np.int64)
+    import ctypes as C
+    from . import _ffi
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
     n = row_ptr.size - 1
-    cut_ok = clean_cuts(row_ptr, col)
-    clean_pos = np.flatnonzero(cut_ok)
-    bounds = [0]
-    for k in range(1, world):
-        ideal = (k * n) // world
-        j = np.searchsorted(clean_pos, ideal)
-        cands = clean_pos[max(0, j - 1): j + 1]
-        best = int(cands[np.argmin(np.abs(cands - ideal))]) if cands.size else ideal
-        if abs(best - ideal) > max(1, int(max_shift_frac * n / world)):
-            best = ideal                                 # no clean cut nearby: keep balance, take a halo
-        bounds.append(max(best, bounds[-1]))
-    bounds.append(n)
-    plan = []
-    for k in range(world):
-        lo, hi = bounds[k], bounds[k + 1]
-        ext_lo, ext_hi = lo, hi
-        if hi > lo:
-            seg = col[row_ptr[lo]:row_ptr[hi]]
-            if seg.size:
-                ext_lo = min(lo, int(seg.min()))
-                ext_hi = max(hi, int(seg.max()) + 1)
-        plan.append(dict(own_lo=lo, own_hi=hi, ext_lo=ext_lo, ext_hi=ext_hi))
-    return plan
+    out = np.zeros((world, 4), dtype=np.int64)
+    vp = C.c_void_p
+    _ffi.check(_ffi.load().sdice_shard_plan(n, row_ptr.ctypes.data_as(vp), col.ctypes.data_as(vp) if col.size else None,
+                                            int(world), float(max_shift_frac), out.ctypes.data_as(vp)), "sdice_shard_plan")
+    return [dict(own_lo=int(a), own_hi=int(b), ext_lo=int(c), ext_hi=int(d)) for a, b, c, d in out]
 
 
 def local_csr(row_ptr, col, part):

@@ -314,3 +314,45 @@ def test_ir_table_without_rsd_table_dies_like_the_reference(golden_dir, tmp_path
     a.makeRSDtable = False
     with pytest.raises(KeyError):          # RSD[sample][junction] is never filled without -r (ir_table.py:140-145)
         ir_table.run_with(a, ctx=_SumEngine())
+
+
+def _shard_plan_numpy(row_ptr, col, world, max_shift_frac=0.02):
+    """the round-1 numpy formulation of the plan (checker for sdice_shard_plan)"""
+    from splicedice_amd import shard
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    n = row_ptr.size - 1
+    clean_pos = np.flatnonzero(shard.clean_cuts(row_ptr, col))
+    bounds = [0]
+    for k in range(1, world):
+        ideal = (k * n) // world
+        j = np.searchsorted(clean_pos, ideal)
+        cands = clean_pos[max(0, j - 1): j + 1]
+        best = int(cands[np.argmin(np.abs(cands - ideal))]) if cands.size else ideal
+        if abs(best - ideal) > max(1, int(max_shift_frac * n / world)):
+            best = ideal
+        bounds.append(max(best, bounds[-1]))
+    bounds.append(n)
+    plan = []
+    for k in range(world):
+        lo, hi = bounds[k], bounds[k + 1]
+        ext_lo, ext_hi = lo, hi
+        if hi > lo:
+            seg = col[row_ptr[lo]:row_ptr[hi]]
+            if seg.size:
+                ext_lo, ext_hi = min(lo, int(seg.min())), max(hi, int(seg.max()) + 1)
+        plan.append(dict(own_lo=lo, own_hi=hi, ext_lo=ext_lo, ext_hi=ext_hi))
+    return plan
+
+
+def test_shard_plan_c_abi_equals_numpy_formulation():
+    from oracle import oracle_np as O
+    from splicedice_amd import shard, synth
+    cases = [synth.make_junctions(5000, 5, n_chrom=2), synth.make_junctions(3000, 6, n_chrom=1, gene_spacing=40, len_span=150000),
+             synth.make_junctions(7, 7), synth.make_junctions(1, 8)]
+    for cr, l, r, st in cases:
+        _, row_ptr, col = O.cluster_csr(cr, l, r, st)
+        for world in (1, 2, 3, 8, 16):
+            for frac in (0.02, 0.0, 0.5):
+                assert shard.shard_plan(row_ptr, col, world, frac) == _shard_plan_numpy(row_ptr, col, world, frac), (cr.size, world, frac)
+    assert shard.shard_plan(np.zeros(1, np.int64), np.zeros(0, np.int32), 3) == [dict(own_lo=0, own_hi=0, ext_lo=0, ext_hi=0)] * 3
