@@ -18,7 +18,6 @@ ap.add_argument("--deg0", action="store_true")
 ap.add_argument("--ablate", type=str, default="0")
 ap.add_argument("--tile_rows", type=str, default="0")
 ap.add_argument("--halo", type=str, default="-1")
-ap.add_argument("--persist", type=str, default="1")
 a = ap.parse_args()
 ctx = Context(0)
 print(ctx.device_info(), flush=True)
@@ -39,7 +38,7 @@ d_counts, d_ps = ctx.to_device(counts), ctx.empty((a.n, a.s), np.float32)
 if a.deg0:
     d_rp = ctx.to_device(np.zeros(a.n + 1, np.int64))
 res = []
-for lds, th, remap, chunk, tr, halo, ab, pers in itertools.product(*[[int(x) for x in v.split(",")] for v in (a.lds, a.threads, a.remap, a.chunk, a.tile_rows, a.halo, a.ablate, a.persist)]):
+for lds, th, remap, chunk, tr, halo, ab in itertools.product(*[[int(x) for x in v.split(",")] for v in (a.lds, a.threads, a.remap, a.chunk, a.tile_rows, a.halo, a.ablate)]):
     ctx.set_param("ps.ablate", ab)
     ctx.set_param("ps.tile_rows", tr); ctx.set_param("ps.halo_rows", halo)
     ctx.set_param("ps.lds_bytes", lds); ctx.set_param("ps.threads", th); ctx.set_param("ps.xcd_remap", remap)
@@ -53,6 +52,6 @@ for lds, th, remap, chunk, tr, halo, ab, pers in itertools.product(*[[int(x) for
     ms /= k
     gbs = a.n * a.s * 8 / ms / 1e6
     res.append((gbs, lds, th, remap, chunk, ms))
-    print("ab=%d tr=%d halo=%d persist=%d " % (ab, tr, halo, pers), end="");print("lds=%6d threads=%4d remap=%d chunk=%3d  %.4f ms  %.1f GB/s (alg)  %.3e entries/s" % (lds, th, remap, chunk, ms, gbs, a.n * a.s / ms * 1e3), flush=True)
+    print("ab=%d tr=%d halo=%d " % (ab, tr, halo), end="");print("lds=%6d threads=%4d remap=%d chunk=%3d  %.4f ms  %.1f GB/s (alg)  %.3e entries/s" % (lds, th, remap, chunk, ms, gbs, a.n * a.s / ms * 1e3), flush=True)
 res.sort(reverse=True)
 print("best", res[0])
