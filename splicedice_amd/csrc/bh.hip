@@ -17,6 +17,10 @@
 #include <algorithm>
 
 int sd_inclusive_min_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, uint64_t* d_out);
+// bh_cols.hip
+size_t sd_bh_cols_scratch(int64_t m, int64_t segs);
+bool sd_bh_cols_supported(int64_t m, int64_t segs);
+int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_cm, double* d_out, int64_t out_pitch);
 
 namespace {
 
@@ -279,12 +283,49 @@ extern "C" int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q) {
 
 // BH down each column of a row-major [n, cols] device table, in place.  Columns are processed in
 // groups so that the scratch (28 bytes per value) stays within `budget` bytes.
+// Columns of up to 2^18 values: sample-sort path (bh_cols.hip).  Column groups are transposed straight out
+// of / back into the row-major table (no dense slab); 30 B of scratch per value.
+static int bh_columns_samplesort(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout) {
+    size_t free_b = 0, total_b = 0;
+    SD_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t arena_b = 0;
+    for (auto& c : ctx->arena.chunks) arena_b += c.cap;
+    const int64_t budget = (int64_t)((free_b + arena_b) / 10 * 9);
+    int64_t group = std::max<int64_t>(1, (budget - (1 << 20)) / (n * 30 + 41 * 1025));
+    if (group > cols) group = cols;
+    for (int64_t c0 = 0; c0 < cols; c0 += group) {
+        const int64_t gc = std::min(group, cols - c0);
+        int rc = ctx->arena.reserve((size_t)n * (size_t)group * 8 + sd_bh_cols_scratch(n, group), ctx->stream);
+        if (rc == SDICE_ERR_NOMEM && group > 1) {            // less memory than hipMemGetInfo promised
+            group = (group + 1) / 2;
+            c0 -= group;
+            continue;
+        }
+        if (rc != SDICE_OK) return rc;
+        double* d_cm = (double*)ctx->arena.alloc((size_t)n * (size_t)gc * 8);
+        if (!d_cm) return SDICE_ERR_NOMEM;
+        const int64_t chunk = (int64_t)65535 * 32;
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t rc_rows = std::min(chunk, n - r0);
+            SD_LAUNCH(ctx, "transpose_f64_kernel", transpose_f64_pitched_kernel,
+                      dim3((unsigned)sd_ceil_div(gc, (int64_t)32), (unsigned)sd_ceil_div(rc_rows, (int64_t)32)), dim3(256), 0,
+                      d_p_inout + r0 * cols + c0, rc_rows, gc, cols, d_cm + r0, n);
+        }
+        SD_TRY(sd_bh_cols_samplesort(ctx, n, gc, d_cm, d_p_inout + c0, cols));
+    }
+    return SDICE_OK;
+}
+
 extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n >= 0 && cols >= 0, "negative size");
     if (n == 0 || cols == 0) return SDICE_OK;
     SD_ARG(d_p_inout, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
+    // bh.columns_path: 0 = by size, 1 = generic radix path, 2 = sample-sort path
+    const int64_t path = ctx->param("bh.columns_path", 0);
+    if (path != 1 && sd_bh_cols_supported(n, cols)) return bh_columns_samplesort(ctx, n, cols, d_p_inout);
+    SD_ARG(path != 2, "bh.columns_path = 2 needs columns of at most 2^18 values");
     // columns per group from what is free right now: per value 2 x 8 B (transposed in / out) + 8 B (dense slab
     // when the columns go in groups) + 37 B of sort scratch + histograms; a failed reservation halves the group
     size_t free_b = 0, total_b = 0;

@@ -522,6 +522,45 @@ def test_bh_columns_batched(ctx, n, cols):
     np.testing.assert_allclose(d.to_host(), O.bh_columns(p), rtol=1e-14, atol=0)
 
 
+@pytest.mark.parametrize("n,cols", [(1, 3), (64, 5), (257, 40), (1024, 9), (1025, 9), (5000, 33), (25000, 12), (70001, 3),
+                                    (200000, 2)])
+def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
+    """the sample-sort column path (bh_cols.hip) against the generic radix path, bit for bit, and the oracle:
+    continuous values, heavy ties (p = 1, a few discrete levels as Fisher gives), one-value and two-value
+    columns, values a few ulps apart, NaN"""
+    rng = np.random.default_rng(n * 31 + cols)
+    p = rng.random((n, cols)) ** 2
+    p[rng.random((n, cols)) < 0.3] = 1.0
+    if cols > 1:
+        p[:, 1] = rng.choice([1.0, 0.5, 0.0286, 0.2, 1e-5], size=n)        # discrete levels
+    if cols > 2:
+        p[:, 2] = 0.25                                                       # one value
+    if cols > 3:
+        p[:, 3] = 0.5 + rng.integers(0, 7, size=n) * 2.0 ** -53              # a few ulps apart
+    if cols > 4 and n > 10:
+        p[rng.integers(0, n, size=3), 4] = np.nan
+    try:
+        ctx.set_param("bh.columns_path", 1)
+        d = ctx.to_device(p)
+        ctx.bh_columns_dev(d)
+        generic = d.to_host()
+        ctx.set_param("bh.columns_path", 2)
+        d = ctx.to_device(p)
+        ctx.bh_columns_dev(d)
+        fast = d.to_host()
+        assert np.array_equal(generic, fast, equal_nan=True)
+        if n > 2000:
+            ctx.set_param("bh.reg_cap", 64)                                   # most buckets through the in-HBM path
+            d = ctx.to_device(p)
+            ctx.bh_columns_dev(d)
+            assert np.array_equal(generic, d.to_host(), equal_nan=True)
+    finally:
+        ctx.set_param("bh.columns_path", 0)
+        ctx.set_param("bh.reg_cap", 1024)
+    ok = ~np.isnan(p).any(axis=0)
+    np.testing.assert_allclose(fast[:, ok], O.bh_columns(p[:, ok]), rtol=1e-14, atol=0)
+
+
 # ------------------------------------------------------------------------------ junction union
 @pytest.mark.parametrize("n,distinct", [(1, 1), (2, 1), (5000, 40), (300_000, 90_000), (1_000_000, 1_000_000)])
 def test_sort_unique_u64(ctx, n, distinct):
