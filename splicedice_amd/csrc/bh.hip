@@ -291,7 +291,7 @@ static int bh_columns_samplesort(sdice_ctx* ctx, int64_t n, int64_t cols, double
     size_t arena_b = 0;
     for (auto& c : ctx->arena.chunks) arena_b += c.cap;
     const int64_t budget = (int64_t)((free_b + arena_b) / 10 * 9);
-    int64_t group = std::max<int64_t>(1, (budget - (1 << 20)) / (n * 30 + 41 * 1025));
+    int64_t group = std::max<int64_t>(1, (budget - (1 << 20)) / (n * 30 + 49 * 1025));
     if (group > cols) group = cols;
     for (int64_t c0 = 0; c0 < cols; c0 += group) {
         const int64_t gc = std::min(group, cols - c0);

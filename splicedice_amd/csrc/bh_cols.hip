@@ -28,7 +28,6 @@
 
 namespace {
 
-constexpr int SPB = 8;              // samples per bucket
 constexpr int TILE_T = 512;         // threads of a count / scatter tile
 constexpr int TILE_E = 8;           // values per thread
 constexpr int TILE = TILE_T * TILE_E;
@@ -39,6 +38,7 @@ struct BhsArgs {
     int64_t m;
     int segs;
     int B;                  // buckets per segment
+    int spb;                // samples per bucket
     int S, S2;              // samples per segment, next power of two
     uint64_t* spl_k;        // [segs][B] (B-1 used)
     uint32_t* spl_i;
@@ -51,6 +51,9 @@ struct BhsArgs {
     uint16_t* bid_cm;       // [segs][m] bucket of each value
     uint64_t* bmin;         // [segs][B]
     uint64_t* sfx;          // [segs][B] minimum over the LATER buckets
+    int abl;
+    unsigned* big_count;    // buckets of more than 256 values: work list of the second bucket kernel
+    int64_t* big_list;      // [segs * B]
     int reg_cap;            // buckets beyond this many values take the in-HBM path (1024; lower in tests)
 };
 
@@ -112,8 +115,8 @@ __global__ void __launch_bounds__(256) bhs_sample_kernel(BhsArgs a) {
         }
     }
     for (int b = tid + 1; b < a.B; b += 256) {
-        a.spl_k[(int64_t)seg * a.B + b - 1] = sk[SPB * b];
-        a.spl_i[(int64_t)seg * a.B + b - 1] = si[SPB * b];
+        a.spl_k[(int64_t)seg * a.B + b - 1] = sk[a.spb * b];
+        a.spl_i[(int64_t)seg * a.B + b - 1] = si[a.spb * b];
     }
 }
 
@@ -282,13 +285,13 @@ __device__ __forceinline__ void bucket_in_regs(const BhsArgs& a, const uint64_t*
             else { key[k] = ks[p]; val[k] = is[p]; }
         }
     }
-    wave_bitonic<K>(key, val, lane);
+    if (!(a.abl & 1)) wave_bitonic<K>(key, val, lane);
     uint64_t s[K];
     uint64_t run = ~0ull;
 #pragma unroll
     for (int k = K - 1; k >= 0; --k) {
         const int p = lane * K + k;
-        const uint64_t r = p < n_b ? raw_bits(key[k], (int64_t)start + p + 1, a.m) : ~0ull;
+        const uint64_t r = p < n_b ? ((a.abl & 4) ? key[k] : raw_bits(key[k], (int64_t)start + p + 1, a.m)) : ~0ull;
         run = r < run ? r : run;
         s[k] = run;
     }
@@ -304,7 +307,7 @@ __device__ __forceinline__ void bucket_in_regs(const BhsArgs& a, const uint64_t*
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int p = lane * K + k;
-        if (p < n_b) {
+        if (p < n_b && (!(a.abl & 2) || s[k] == 12345)) {
             const uint64_t v = s[k] < ex ? s[k] : ex;
             a.q_cm[seg_off + val[k]] = v;
             a.bid_cm[seg_off + val[k]] = (uint16_t)bucket;
@@ -361,31 +364,65 @@ __device__ void bucket_in_hbm(const BhsArgs& a, uint64_t* ks, uint32_t* is, int 
     if (lane == 0) *bmin_out = carry;
 }
 
+// what a wave needs to know about bucket g
+struct BucketRef {
+    int seg, b, n_b;
+    unsigned start;
+    int64_t seg_off;
+    const double* pd;
+    uint64_t* ks;
+    uint32_t* is;
+    uint64_t* bm;
+};
+__device__ __forceinline__ BucketRef bucket_ref(const BhsArgs& a, int64_t g) {
+    BucketRef r;
+    r.seg = (int)(g / a.B);
+    r.b = (int)(g - (int64_t)r.seg * a.B);
+    r.seg_off = (int64_t)r.seg * a.m;
+    r.start = 0;
+    r.n_b = (int)a.m;
+    r.pd = nullptr; r.ks = nullptr; r.is = nullptr;
+    if (a.B == 1) {
+        r.pd = a.p_cm + r.seg_off;                 // short segments: no partition, straight from the p-values
+    } else {
+        r.start = a.start[(int64_t)r.seg * (a.B + 1) + r.b];
+        r.n_b = (int)(a.start[(int64_t)r.seg * (a.B + 1) + r.b + 1] - r.start);
+        r.ks = a.keyS + r.seg_off + r.start;
+        r.is = a.idxS + r.seg_off + r.start;
+    }
+    r.bm = a.bmin + (int64_t)r.seg * a.B + r.b;
+    return r;
+}
+
+// buckets of up to 256 values (nearly all of them): 4 keys per lane, ~40 VGPRs, 8 waves per SIMD.
+// Larger buckets go to a work list for bhs_bucket_big_kernel (whose 16-keys-per-lane network needs
+// 150 VGPRs: in one kernel it held every wave to 3 per SIMD and the loads' latency was not hidden).
 __global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int64_t n_buckets) {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_buckets) return;
-    const int seg = (int)(g / a.B), b = (int)(g - (int64_t)seg * a.B);
-    const int64_t seg_off = (int64_t)seg * a.m;
-    unsigned start = 0;
-    int n_b = (int)a.m;
-    const double* pd = nullptr;
-    uint64_t* ks = nullptr;
-    uint32_t* is = nullptr;
-    if (a.B == 1) {
-        pd = a.p_cm + seg_off;                     // short segments: no partition, straight from the p-values
-    } else {
-        start = a.start[(int64_t)seg * (a.B + 1) + b];
-        n_b = (int)(a.start[(int64_t)seg * (a.B + 1) + b + 1] - start);
-        ks = a.keyS + seg_off + start;
-        is = a.idxS + seg_off + start;
+    const BucketRef r = bucket_ref(a, g);
+    if (r.n_b <= 256 && r.n_b <= a.reg_cap) {
+        bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+    } else if (lane == 0) {
+        const unsigned slot = atomicAdd(a.big_count, 1u);
+        a.big_list[slot] = g;
     }
-    uint64_t* bm = a.bmin + (int64_t)seg * a.B + b;
-    if (n_b > a.reg_cap && !pd) bucket_in_hbm(a, ks, is, n_b, seg_off, start, b, lane, bm);
-    else if (n_b <= 256) bucket_in_regs<4>(a, ks, is, pd, n_b, seg_off, start, b, lane, bm);
-    else if (n_b <= 512) bucket_in_regs<8>(a, ks, is, pd, n_b, seg_off, start, b, lane, bm);
-    else if (n_b <= 1024) bucket_in_regs<16>(a, ks, is, pd, n_b, seg_off, start, b, lane, bm);
-    else bucket_in_hbm(a, ks, is, n_b, seg_off, start, b, lane, bm);
+}
+
+__global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n_big = *a.big_count;
+    const unsigned waves = gridDim.x * 4;
+#pragma nounroll
+    for (unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_big; w += waves) {
+        const BucketRef r = bucket_ref(a, a.big_list[w]);
+        if (r.n_b > a.reg_cap && !r.pd) bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+        else if (r.n_b <= 256) bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+        else if (r.n_b <= 512) bucket_in_regs<8>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+        else if (r.n_b <= 1024) bucket_in_regs<16>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+        else bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+    }
 }
 
 // ---------------------------------------------------------------- 6. minima of the later buckets
@@ -442,7 +479,7 @@ __global__ void __launch_bounds__(256) bhs_finish_kernel(BhsArgs a, double* __re
 // scratch bytes the sample-sort path needs for `segs` segments of m values (without the transposed input)
 size_t sd_bh_cols_scratch(int64_t m, int64_t segs) {
     const size_t vals = (size_t)m * (size_t)segs;
-    return vals * 22 + (size_t)segs * (size_t)(MAX_B + 1) * 40 + (1 << 16);
+    return vals * 22 + (size_t)segs * (size_t)(MAX_B + 1) * 48 + (1 << 16);
 }
 
 bool sd_bh_cols_supported(int64_t m, int64_t segs) {
@@ -459,13 +496,18 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     a.segs = (int)segs;
     int B = 1;
     if (m > 1024) {
-        int64_t mean = std::max<int64_t>(160, sd_ceil_div(m, (int64_t)MAX_B));
+        int64_t mean = std::max<int64_t>(ctx->param("bh.mean", 160), sd_ceil_div(m, (int64_t)MAX_B));
         B = (int)sd_ceil_div(m, mean);
         if (B > MAX_B) B = MAX_B;
     }
     a.B = B;
+    a.abl = (int)ctx->param("bh.ablate", 0);
     a.reg_cap = (int)std::min<int64_t>(1024, std::max<int64_t>(0, ctx->param("bh.reg_cap", 1024)));
-    a.S = SPB * B;
+    a.spb = (int)ctx->param("bh.spb", 8);
+    if (a.spb < 1) a.spb = 1;
+    while (a.spb > 1 && (int64_t)a.spb * B > 8192) a.spb >>= 1;      // the sample is sorted in 96 KB of LDS
+    while (a.spb > 1 && (int64_t)a.spb * B * 2 > m) a.spb >>= 1;
+    a.S = a.spb * B;
     a.S2 = 1;
     while (a.S2 < a.S) a.S2 <<= 1;
     const size_t vals = (size_t)m * (size_t)segs;
@@ -479,9 +521,11 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     a.start = (unsigned*)A.alloc((size_t)segs * (size_t)(B + 1) * 4);
     a.q_cm = (uint64_t*)A.alloc(vals * 8);
     a.bid_cm = (uint16_t*)A.alloc(vals * 2);
+    a.big_list = (int64_t*)A.alloc(sb * 8);
+    a.big_count = (unsigned*)A.alloc(8);
     a.keyS = B > 1 ? (uint64_t*)A.alloc(vals * 8) : nullptr;
     a.idxS = B > 1 ? (uint32_t*)A.alloc(vals * 4) : nullptr;
-    if (!a.spl_k || !a.bmin || !a.sfx || !a.spl_i || !a.gcount || !a.cursor || !a.start || !a.q_cm || !a.bid_cm ||
+    if (!a.spl_k || !a.bmin || !a.sfx || !a.spl_i || !a.gcount || !a.cursor || !a.start || !a.q_cm || !a.bid_cm || !a.big_list || !a.big_count ||
         (B > 1 && (!a.keyS || !a.idxS)))
         return SDICE_ERR_NOMEM;
     if (B > 1) {
@@ -510,8 +554,11 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     }
     const int64_t n_buckets = segs * B;
     SD_ARG(sd_ceil_div(n_buckets, (int64_t)4) < ((int64_t)1 << 31), "bh: too many buckets");
+    SD_HIP(hipMemsetAsync(a.big_count, 0, 8, ctx->stream));
     SD_LAUNCH(ctx, "bhs_bucket_kernel", bhs_bucket_kernel, dim3((unsigned)sd_ceil_div(n_buckets, (int64_t)4)), dim3(256), 0, a,
               n_buckets);
+    SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel,
+              dim3((unsigned)std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4)), dim3(256), 0, a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);
     const int64_t gx = sd_ceil_div(m, (int64_t)32);
     for (int64_t c0 = 0; c0 < segs; c0 += (int64_t)65535 * 32) {
