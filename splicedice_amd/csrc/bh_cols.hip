@@ -51,7 +51,6 @@ struct BhsArgs {
     uint16_t* bid_cm;       // [segs][m] bucket of each value
     uint64_t* bmin;         // [segs][B]
     uint64_t* sfx;          // [segs][B] minimum over the LATER buckets
-    int abl;
     unsigned* big_count;    // buckets of more than 256 values: work list of the second bucket kernel
     int64_t* big_list;      // [segs * B]
     int reg_cap;            // buckets beyond this many values take the in-HBM path (1024; lower in tests)
@@ -285,13 +284,13 @@ __device__ __forceinline__ void bucket_in_regs(const BhsArgs& a, const uint64_t*
             else { key[k] = ks[p]; val[k] = is[p]; }
         }
     }
-    if (!(a.abl & 1)) wave_bitonic<K>(key, val, lane);
+    wave_bitonic<K>(key, val, lane);
     uint64_t s[K];
     uint64_t run = ~0ull;
 #pragma unroll
     for (int k = K - 1; k >= 0; --k) {
         const int p = lane * K + k;
-        const uint64_t r = p < n_b ? ((a.abl & 4) ? key[k] : raw_bits(key[k], (int64_t)start + p + 1, a.m)) : ~0ull;
+        const uint64_t r = p < n_b ? raw_bits(key[k], (int64_t)start + p + 1, a.m) : ~0ull;
         run = r < run ? r : run;
         s[k] = run;
     }
@@ -307,7 +306,7 @@ __device__ __forceinline__ void bucket_in_regs(const BhsArgs& a, const uint64_t*
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int p = lane * K + k;
-        if (p < n_b && (!(a.abl & 2) || s[k] == 12345)) {
+        if (p < n_b) {
             const uint64_t v = s[k] < ex ? s[k] : ex;
             a.q_cm[seg_off + val[k]] = v;
             a.bid_cm[seg_off + val[k]] = (uint16_t)bucket;
@@ -501,7 +500,6 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
         if (B > MAX_B) B = MAX_B;
     }
     a.B = B;
-    a.abl = (int)ctx->param("bh.ablate", 0);
     a.reg_cap = (int)std::min<int64_t>(1024, std::max<int64_t>(0, ctx->param("bh.reg_cap", 1024)));
     a.spb = (int)ctx->param("bh.spb", 8);
     if (a.spb < 1) a.spb = 1;
