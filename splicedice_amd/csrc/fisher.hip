@@ -15,6 +15,7 @@
 // The kernel is f64-VALU bound (O(support) steps per p-value), not HBM bound.
 #include "common.h"
 #include <math.h>
+#include <algorithm>
 
 namespace {
 
@@ -23,8 +24,12 @@ struct LfTable {
     long long n;
 };
 
+// beyond the table (margins above fisher.table_max): a real call, so that the nine look-ups of a
+// p-value do not inline nine copies of lgamma and their registers into the kernels
+__device__ __noinline__ double lgamma_beyond_table(double x) { return lgamma(x); }
+
 __device__ __forceinline__ double logfact(const LfTable& t, long long k) {
-    return k < t.n ? t.lf[k] : lgamma((double)k + 1.0);
+    return k < t.n ? t.lf[k] : lgamma_beyond_table((double)k + 1.0);
 }
 
 // 1/y for y an integer-valued double in [1, 2^63): hardware seed + two Newton steps (no scaling or
@@ -39,30 +44,61 @@ __device__ __forceinline__ double rcp_pos(double y) {
     return fma(x, e, x);
 }
 
-// one-directional walk of the ratios; dir = +1 (k increasing) or -1
-template <int DIR>
-__device__ __forceinline__ double walk_side(double a, double n1, double n2, double n, double bound_steps) {
-    // up:   rho = (n1-k)(n-k) / ((k+1)(n2-n+k+1))
-    // down: rho = k (n2-n+k) / ((n1-k+1)(n-k+1))
-    double u1, u2, v1, v2;   // numerator factors u (decreasing by 1 per step), denominator factors v (increasing)
-    if (DIR > 0) { u1 = n1 - a; u2 = n - a; v1 = a + 1.0; v2 = n2 - n + a + 1.0; }
-    else { u1 = a; u2 = n2 - n + a; v1 = n1 - a + 1.0; v2 = n - a + 1.0; }
-    const double slack = 1.0 + 1e-12;
-    double r = 1.0, total = 0.0;
-    int e = 0;   // r is scaled by 2^(500 e) while it is astronomically above 1
-    for (double t = 0.0; t < bound_steps; t += 1.0) {
-        const double rho = (u1 * u2) * rcp_pos(v1 * v2);
-        r *= rho;
-        u1 -= 1.0; u2 -= 1.0; v1 += 1.0; v2 += 1.0;
-        if (r > 0x1p500) { r *= 0x1p-500; ++e; }
-        else if (e > 0 && r < 0x1p-100) { r *= 0x1p500; --e; }
-        if (e == 0 && r <= slack) {
-            total += r;
-            if (rho < 0.5 && r < 1e-18 * (1.0 + total)) break;
-        }
+// One-directional walk of the ratios r_k = pmf(k)/pmf(a) away from k = a.
+//   up:   rho = (n1-k)(n-k) / ((k+1)(n2-n+k+1))        down: rho = k (n2-n+k) / ((n1-k+1)(n-k+1))
+// Both are (u1 u2)/(v1 v2) with u falling and v rising by one per step, so one step routine serves both.
+// No division per step: r_k = P_k/Q_k with P = prod(u1 u2), Q = prod(v1 v2), and the accepted ratios are
+// summed over the common denominator, S_k = S_{k-1} (v1 v2) + [accepted] P_k, so the side's sum is S/Q --
+// one reciprocal per side instead of one per step (the reciprocal and its Newton steps were a third of a
+// step).  "Accepted" (pmf(k) <= pmf(a) (1 + 1e-12)) is P <= slack Q; the products carry a few 1e-16 of
+// rounding per step, like the ratio recurrence they replace.  P, Q and S are rescaled by powers of two
+// (exact); while P is scaled by 2^(500 eP) relative to Q the ratio is astronomically above 1.
+struct Walk {
+    double u1, u2, v1, v2, P, Q, S, u1_end;
+    int eP;
+    // P carries a factor 1/slack, so that "accepted" is simply P <= Q; sum() puts it back
+    static constexpr double SLACK = 1.0 + 1e-12, INV_SLACK = 1.0 / (1.0 + 1e-12);
+    __device__ __forceinline__ void start(double u1_, double u2_, double v1_, double v2_, double steps) {
+        u1 = u1_; u2 = u2_; v1 = v1_; v2 = v2_;
+        u1_end = u1_ - steps;
+        P = INV_SLACK; Q = 1.0; S = 0.0; eP = 0;
     }
-    return total;
-}
+    // the walk on the other side of a continues on the same denominator: r = 1 again means P = Q / slack,
+    // and S / Q ends as the sum over both sides
+    __device__ __forceinline__ void turn(double u1_, double u2_, double v1_, double v2_, double steps) {
+        u1 = u1_; u2 = u2_; v1 = v1_; v2 = v2_;
+        u1_end = u1_ - steps;
+        P = Q * INV_SLACK; eP = 0;
+    }
+    // one step; true when no step is left on this side
+    __device__ __forceinline__ bool step() {
+        if (!(u1 > u1_end)) return true;
+        const double N = u1 * u2, D = v1 * v2;
+        P *= N; Q *= D;
+        u1 -= 1.0; u2 -= 1.0; v1 += 1.0; v2 += 1.0;
+        const bool acc = eP == 0 && P <= Q;
+        S = fma(S, D, acc ? P : 0.0);
+        return false;
+    }
+    // what remains of this side is below 1e-18 of the sum: the next ratio of ratios is below 1/2 and falls
+    // from here on (the pmf is log-concave), so the rest is less than the last accepted term
+    __device__ __forceinline__ bool tail_negligible() const {
+        return eP == 0 && P <= Q && 2.0 * (u1 * u2) < v1 * v2 && P < 1e-18 * (Q + S);
+    }
+    // at least every 4 steps (a step multiplies P and Q by less than 2^62)
+    __device__ __forceinline__ void rescale() {
+        if (Q > 0x1p500) { P *= 0x1p-500; Q *= 0x1p-500; S *= 0x1p-500; }
+        if (P > 0x1p760) { P *= 0x1p-500; ++eP; }
+        else if (eP > 0 && P < 0x1p260) { P *= 0x1p500; --eP; }
+    }
+    // slack S / Q, Q in [1, 2^750): hardware seed (~2^-23) + one Newton step -> ~1e-14, against a tolerance of 1e-9
+    __device__ __forceinline__ double sum() const {
+        double x = __builtin_amdgcn_rcp(Q);
+        const double e = fma(-Q, x, 1.0);
+        x = fma(x, e, x);
+        return (S * SLACK) * x;
+    }
+};
 
 __device__ double fisher_two_sided(long long a, long long b, long long c, long long d, const LfTable& t) {
     const long long n1 = a + b, n2 = c + d, n = a + c, m = b + d;
@@ -74,9 +110,12 @@ __device__ double fisher_two_sided(long long a, long long b, long long c, long l
                         logfact(t, a) - logfact(t, n1 - a) - logfact(t, n - a) - logfact(t, n2 - n + a);
     const double pexact = exp(logp);
     const double da = (double)a, dn1 = (double)n1, dn2 = (double)n2, dn = (double)n;
-    double total = 1.0;
-    total += walk_side<-1>(da, dn1, dn2, dn, (double)(a - lo));
-    total += walk_side<+1>(da, dn1, dn2, dn, (double)(hi - a));
+    Walk w;
+    w.start(da, dn2 - dn + da, dn1 - da + 1.0, dn - da + 1.0, (double)(a - lo));                 // down from k = a
+    while (!w.step()) { w.rescale(); if (w.tail_negligible()) break; }
+    w.turn(dn1 - da, dn - da, da + 1.0, dn2 - dn + da + 1.0, (double)(hi - a));                    // up from k = a
+    while (!w.step()) { w.rescale(); if (w.tail_negligible()) break; }
+    const double total = 1.0 + w.sum();
     const double p = pexact * total;
     return p < 1.0 ? p : 1.0;
 }
@@ -93,32 +132,142 @@ __global__ void __launch_bounds__(256) fisher_tables_kernel(const int64_t* __res
     p[i] = fisher_two_sided(abcd[4 * i], abcd[4 * i + 1], abcd[4 * i + 2], abcd[4 * i + 3], t);
 }
 
-// one workgroup per junction; pairs q = (i, j), i < j, row-major (pairwise_fisher.py:142-147)
-__global__ void __launch_bounds__(256) fisher_pairs_kernel(const int32_t* __restrict__ incl,
-                                                           const int64_t* __restrict__ excl, int64_t n, int s,
-                                                           double* __restrict__ p, LfTable t) {
-    extern __shared__ long long sm[];
-    long long* inc = sm;
-    long long* exc = sm + s;
+// pair index q -> (i, j), i < j, row-major (pairwise_fisher.py:142-147): q = i*s - i(i+1)/2 + (j-i-1)
+__device__ __forceinline__ void pair_of(int64_t q, int s, int& i, int& j) {
+    const double bb = 2.0 * s - 1.0;
+    i = (int)((bb - sqrt(bb * bb - 8.0 * (double)q)) * 0.5);
+    if (i < 0) i = 0;
+    if (i > s - 2) i = s - 2;
+    while (i > 0 && (int64_t)i * s - (int64_t)i * (i + 1) / 2 > q) --i;
+    while ((int64_t)(i + 1) * s - (int64_t)(i + 1) * (i + 2) / 2 <= q) ++i;
+    j = (int)(q - ((int64_t)i * s - (int64_t)i * (i + 1) / 2)) + i + 1;
+}
+
+// One WAVE per junction.  The walk lengths of the pairs of one junction differ by an order of
+// magnitude (they follow the margins), and a loop "for each pair: walk" keeps a wave at the pace of its
+// slowest lane: 27 of 64 lanes were active on average.  Here every lane runs its own stream of pairs
+// q = lane, lane + 64, ... as a small state machine -- idle / walking down / walking up -- and the wave
+// executes walk steps for whoever is walking.  Lanes that finish a pair wait until `refill` of them are
+// idle (the set-up of a pair is ~100 instructions that the whole wave issues), then fetch their next
+// pair together.  Over the ~300 pairs of a lane the lengths average out, so the lanes finish a
+// junction within a few per cent of each other.  The state machine only produces the sum of the ratios;
+// pmf(a) -- nine log-factorial look-ups and an exp -- is applied afterwards in a pass with all lanes busy.
+// (i << 16 | j) of every pair index: the same for every junction, built once per call shape
+__global__ void __launch_bounds__(256) pair_table_kernel(unsigned* __restrict__ tab, int64_t n_pairs, int s) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_pairs) return;
+    int i, j;
+    pair_of(q, s, i, j);
+    tab[q] = ((unsigned)i << 16) | (unsigned)j;
+}
+
+__device__ __forceinline__ double logfact_d(const LfTable& t, double k) {
+    return k < (double)t.n ? t.lf[(int)k] : lgamma_beyond_table(k + 1.0);
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
+fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict__ excl, int64_t n, int s,
+                    double* __restrict__ p, LfTable tab, const unsigned* __restrict__ pair_tab, int refill,
+                    unsigned long long* __restrict__ row_counter) {
+    // counts staged as doubles (exact below 2^53): the set-up of a pair is then a table look-up, four LDS
+    // reads and a dozen f64 operations, no integer -> double conversions
+    extern __shared__ double smd[];
+    double* inc = smd;
+    double* exc = smd + s;
+    const int lane = threadIdx.x;
     const int64_t n_pairs = (int64_t)s * (s - 1) / 2;
-    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+    static_assert(UNROLL >= 1 && UNROLL <= 8, "unroll");
+    while (true) {
+        // junctions are handed out one at a time: the grid is the set of resident waves, and a wave that
+        // drew cheap junctions takes more of them
+        unsigned long long row_u = 0;
+        if (lane == 0) row_u = atomicAdd(row_counter, 1ull);
+        const int64_t row = (int64_t)__shfl((long long)row_u, 0);
+        if (row >= n) break;
         __syncthreads();
-        for (int k = threadIdx.x; k < s; k += blockDim.x) {
-            inc[k] = incl[row * s + k];
-            exc[k] = excl[row * s + k];
+        for (int k = lane; k < s; k += 64) {
+            inc[k] = (double)incl[row * s + k];
+            exc[k] = (double)excl[row * s + k];
         }
         __syncthreads();
         double* out = p + row * n_pairs;
-        for (int64_t q = threadIdx.x; q < n_pairs; q += blockDim.x) {
-            // invert q = i*s - i(i+1)/2 + (j-i-1)
-            const double bb = 2.0 * s - 1.0;
-            int i = (int)((bb - sqrt(bb * bb - 8.0 * (double)q)) * 0.5);
-            if (i < 0) i = 0;
-            if (i > s - 2) i = s - 2;
-            while (i > 0 && (int64_t)i * s - (int64_t)i * (i + 1) / 2 > q) --i;
-            while ((int64_t)(i + 1) * s - (int64_t)(i + 1) * (i + 2) / 2 <= q) ++i;
-            const int j = (int)(q - ((int64_t)i * s - (int64_t)i * (i + 1) / 2)) + i + 1;
-            out[q] = fisher_two_sided(inc[i], inc[j], exc[i], exc[j], t);
+
+        // ---- sums of the ratios: out[q] = 1 + sum over the accepted k != a of pmf(k)/pmf(a); -1 = a zero margin
+        int64_t q_next = lane, q_cur = 0;
+        unsigned ij_next = q_next < n_pairs ? pair_tab[q_next] : 0u;   // always one entry ahead: its latency hides behind a walk
+        int phase = 0;                         // 0 idle, 1 walking down from a, 2 walking up from a
+        Walk w;
+        w.start(0.0, 0.0, 0.0, 0.0, 0.0);
+        double up_steps = 0.0, a_cur = 0.0, n1_cur = 0.0, n2_cur = 0.0, nn_cur = 0.0;
+        while (true) {
+            const bool can_fetch = phase == 0 && q_next < n_pairs;
+            const unsigned long long idle_m = __ballot(phase == 0), fetch_m = __ballot(can_fetch);
+            if (idle_m == ~0ull && fetch_m == 0ull) break;
+            if (__popcll(fetch_m) >= refill || idle_m == ~0ull) {
+                if (can_fetch) {
+                    for (int tries = 0; tries < 4 && phase == 0 && q_next < n_pairs; ++tries) {
+                        const int i = (int)(ij_next >> 16), j = (int)(ij_next & 0xffffu);
+                        const double a = inc[i], b = inc[j], c = exc[i], d = exc[j];
+                        const double n1 = a + b, n2 = c + d, nn = a + c, mm = b + d;
+                        q_cur = q_next;
+                        q_next += 64;
+                        if (q_next < n_pairs) ij_next = pair_tab[q_next];
+                        if (n1 == 0.0 || n2 == 0.0 || nn == 0.0 || mm == 0.0) {
+                            out[q_cur] = -1.0;                     // scipy: p = 1
+                        } else {
+                            const double lo = nn - n2 > 0.0 ? nn - n2 : 0.0, hi = n1 < nn ? n1 : nn;
+                            a_cur = a; n1_cur = n1; n2_cur = n2; nn_cur = nn;
+                            up_steps = hi - a;
+                            if (a > lo) {
+                                w.start(a, n2 - nn + a, n1 - a + 1.0, nn - a + 1.0, a - lo);   // down from k = a
+                                phase = 1;
+                            } else {                                                           // nothing below a
+                                w.start(n1 - a, nn - a, a + 1.0, n2 - nn + a + 1.0, up_steps);
+                                phase = 2;
+                            }
+                        }
+                    }
+                }
+            }
+            bool act = phase != 0, fin = false;
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                if (act && w.step()) { fin = true; act = false; }
+                if (k % 4 == 3 && k + 1 < UNROLL && act) w.rescale();
+            }
+            if (act) {
+                w.rescale();
+                fin = w.tail_negligible();
+            }
+            if (fin) {
+                if (phase == 1) {
+                    w.turn(n1_cur - a_cur, nn_cur - a_cur, a_cur + 1.0, n2_cur - nn_cur + a_cur + 1.0, up_steps);   // up
+                    phase = 2;
+                } else {
+                    out[q_cur] = 1.0 + w.sum();
+                    phase = 0;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- p = pmf(a) * sum, all lanes busy
+        for (int64_t q = lane; q < n_pairs; q += 64) {
+            const double total = out[q];
+            double pv = 1.0;
+            if (total >= 0.0) {
+                const unsigned ij = pair_tab[q];
+                const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+                const double a = inc[i], b = inc[j], c = exc[i], d = exc[j];
+                const double n1 = a + b, n2 = c + d, nn = a + c, M = n1 + n2;
+                const double logp = logfact_d(tab, n1) + logfact_d(tab, n2) + logfact_d(tab, nn) + logfact_d(tab, M - nn) -
+                                    logfact_d(tab, M) - logfact_d(tab, a) - logfact_d(tab, n1 - a) - logfact_d(tab, nn - a) -
+                                    logfact_d(tab, n2 - nn + a);
+                pv = exp(logp) * total;
+                pv = pv < 1.0 ? pv : 1.0;
+            }
+            out[q] = pv;
         }
     }
 }
@@ -164,18 +313,28 @@ extern "C" int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, cons
     SD_HIP(hipSetDevice(ctx->device));
     LfTable t;
     SD_TRY(get_lf_table(ctx, &t));
-    int threads = (int)ctx->param("fisher.threads", 256);
-    threads = (threads / 64) * 64;
-    if (threads < 64) threads = 64;
-    if (threads > 256) threads = 256;
-    int64_t blocks = n;
-    const int64_t cap = (int64_t)ctx->n_cu * 32;
-    if (blocks > cap) blocks = cap;
+    int refill = (int)ctx->param("fisher.refill", 16);
+    if (refill < 1) refill = 1;
+    if (refill > 64) refill = 64;
+    const int unroll = (int)ctx->param("fisher.unroll", 8);
+    const int64_t n_pairs = (int64_t)s * (s - 1) / 2;
+    SD_TRY(ctx->arena.reserve((size_t)n_pairs * 4 + 8192, ctx->stream));
+    unsigned* pair_tab = (unsigned*)ctx->arena.alloc((size_t)n_pairs * 4);
+    unsigned long long* row_counter = (unsigned long long*)ctx->arena.alloc(8);
+    if (!pair_tab || !row_counter) return SDICE_ERR_NOMEM;
+    SD_HIP(hipMemsetAsync(row_counter, 0, 8, ctx->stream));
+    SD_LAUNCH(ctx, "pair_table_kernel", pair_table_kernel, dim3((unsigned)sd_ceil_div(n_pairs, (int64_t)256)), dim3(256), 0,
+              pair_tab, n_pairs, (int)s);
     const size_t lds = (size_t)s * 16;
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fisher_pairs_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "fisher_pairs_kernel", fisher_pairs_kernel, dim3((unsigned)blocks), dim3(threads), lds, d_incl, d_excl,
-              n, (int)s, d_p, t);
+    auto kern = unroll <= 1 ? fisher_pairs_kernel<1> : unroll == 2 ? fisher_pairs_kernel<2> : unroll <= 4 ? fisher_pairs_kernel<4> :
+                unroll <= 6 ? fisher_pairs_kernel<6> : fisher_pairs_kernel<8>;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    SD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = std::min<int64_t>(n, (int64_t)ctx->n_cu * per_cu);     // the resident waves; junctions by counter
+    SD_LAUNCH(ctx, "fisher_pairs_kernel", kern, dim3((unsigned)blocks), dim3(64), lds, d_incl, d_excl, n, (int)s, d_p, t,
+              pair_tab, refill, row_counter);
     return SDICE_OK;
 }
 
