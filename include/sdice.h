@@ -186,10 +186,27 @@ int sdice_write_table(const char* path, const char* header /* incl. '\n' */, int
  * (compareSampleSets.py:252-270). */
 int sdice_write_columns(const char* path, const char* header, int64_t n, const char* names, const int64_t* name_off,
                         int32_t ncols, const void* const* cols, const int32_t* dtypes, const int32_t* modes, int threads);
+/* sdice_write_columns with a ready-made text suffix per row (written after the last numeric column): the
+ * gene / overlapping / transcript_id columns of an annotated table (compareSampleSets.py:238-264). */
+int sdice_write_columns_sfx(const char* path, const char* header, int64_t n, const char* names, const int64_t* name_off,
+                            int32_t ncols, const void* const* cols, const int32_t* dtypes, const int32_t* modes,
+                            const char* sfx, const int64_t* sfx_off, int threads);
+/* The interval scan of the GTF annotation join (compareSampleSets.py:246-252): event e (group ev_group[e], -1 =
+ * none; positions ev_a[e], ev_b[e]) matches interval k of its group (grp_ptr CSR over lo[] / hi[]) when
+ * lo <= a <= hi or lo <= b <= hi.  out_idx == NULL: fill out_ptr[0..n_events] with the prefix sums of the match
+ * counts; otherwise also write the matching interval indices (increasing k per event). */
+int sdice_interval_overlaps(int64_t n_events, const int32_t* ev_group, const int64_t* ev_a, const int64_t* ev_b,
+                            int32_t n_groups, const int64_t* grp_ptr, const int64_t* lo, const int64_t* hi,
+                            int64_t* out_ptr, int64_t* out_idx, int64_t out_cap, int threads);
 /* `<prefix>_allClusters.tsv` (SPLICEDICE.py:316-326): name<TAB>comma-joined names of the row's
  * neighbour list (CSR in row indices), one line per junction row. */
 int sdice_write_clusters(const char* path, int64_t n, const char* names, const int64_t* name_off,
                          const int64_t* row_ptr, const int32_t* col, int threads);
+/* `<prefix>_junctions.bed` (SPLICEDICE.py:316-321): chrom<TAB>left<TAB>right<TAB>chrom:left-right:strand<TAB>0<TAB>strand
+ * per junction row; chrom[r] indexes the n_chrom names in chrom_names / chrom_off, strand[r] is the character. */
+int sdice_write_junction_bed(const char* path, int64_t n, const char* chrom_names, const int64_t* chrom_off,
+                             int32_t n_chrom, const int32_t* chrom, const int32_t* left, const int32_t* right,
+                             const char* strand, int threads);
 typedef struct sdice_table sdice_table;
 int sdice_table_open(const char* path, sdice_table** out, int64_t* n, int32_t* s, int64_t* names_bytes,
                      int64_t* header_bytes);

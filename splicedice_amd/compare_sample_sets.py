@@ -74,6 +74,43 @@ def read_annotation(gtf_path):
     return annotated, gene_coords, transcript_ids
 
 
+def annotation_suffixes(names, gtf_path):
+    """'\\tgene\\toverlapping\\ttranscript_id' for every event name (compareSampleSets.py:238-264).  The reference
+    walks all gene intervals of the event's (chromosome, strand) per event in Python; here that scan is the
+    library's threaded interval join (sdice_interval_overlaps) and the known-junction look-ups stay dict
+    look-ups; order of the listed genes = the reference's (dict order of the intervals, file order inside)."""
+    from . import textio
+    annotated, gene_coords, transcript_ids = read_annotation(gtf_path)
+    groups = {key: g for g, key in enumerate(gene_coords)}
+    grp_ptr = np.zeros(len(groups) + 1, dtype=np.int64)
+    lo, hi, key_names = [], [], []
+    for g, intervals in enumerate(gene_coords.values()):
+        for (gene_start, gene_stop), gene_names in intervals.items():
+            lo.append(gene_start)
+            hi.append(gene_stop)
+            key_names.append(",".join(gene_names))
+        grp_ptr[g + 1] = len(lo)
+    ev_group = np.empty(len(names), dtype=np.int32)
+    ev_a = np.empty(len(names), dtype=np.int64)
+    ev_b = np.empty(len(names), dtype=np.int64)
+    junctions = []
+    for n, name in enumerate(names):
+        chromosome, coords, strand = name.split(":")
+        start, stop = (int(x) for x in coords.split("-"))
+        start -= 1
+        stop += 1
+        junctions.append((chromosome, start, stop, strand))
+        ev_group[n] = groups.get((chromosome, strand), -1)
+        ev_a[n] = start
+        ev_b[n] = stop
+    ptr, idx = textio.interval_overlaps(ev_group, ev_a, ev_b, grp_ptr, lo, hi)
+    ptr = ptr.tolist()
+    idx = idx.tolist()
+    nan = ["nan"]
+    return ["\t" + ",".join(annotated.get(j, nan)) + "\t" + ",".join(key_names[k] for k in idx[ptr[n]:ptr[n + 1]]) +
+            "\t" + ",".join(transcript_ids.get(j, nan)) for n, j in enumerate(junctions)]
+
+
 def compare(matrix, g1_idx, g2_idx, ctx):
     """-> (kept row indices, dict of compacted per-row results incl. BH-corrected p)."""
     res = ctx.ranksum(matrix, g1_idx, g2_idx)
@@ -148,29 +185,11 @@ def run_with(args, ctx=None):
                              [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
                              ["repr"] * 7)
         return
-    with open(args.outputFile, "w") as tsv:
-        if args.annotation:
-            print(base_header + "\tgene\toverlapping\ttranscript_id", file=tsv)
-            annotated, gene_coords, transcript_ids = read_annotation(args.annotation)
-        else:
-            print(base_header, file=tsv)
-        for n, ri in enumerate(keep):
-            name = rows[ri]
-            fields = [name, r["mean1"][n], r["mean2"][n], r["med1"][n], r["med2"][n], r["delta"][n], r["p"][n],
-                      r["corrected"][n]]
-            if args.annotation:
-                chromosome, coords, strand = name.split(":")
-                start, stop = (int(x) for x in coords.split("-"))
-                start -= 1
-                stop += 1
-                junction = (chromosome, start, stop, strand)
-                overlaps = []
-                for (gene_start, gene_stop), gene_names in gene_coords.get((chromosome, strand), {}).items():
-                    if gene_start <= start <= gene_stop or gene_start <= stop <= gene_stop:
-                        overlaps.extend(gene_names)
-                fields += [",".join(annotated.get(junction, ["nan"])), ",".join(overlaps),
-                           ",".join(transcript_ids.get(junction, ["nan"]))]
-            print(*fields, sep="\t", file=tsv)
+    from . import textio
+    names = [rows[ri] for ri in keep]
+    textio.write_columns(args.outputFile, base_header + "\tgene\toverlapping\ttranscript_id\n", names,
+                         [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
+                         ["repr"] * 7, suffixes=annotation_suffixes(names, args.annotation))
 
 
 if __name__ == "__main__":

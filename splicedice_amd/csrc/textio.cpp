@@ -210,10 +210,12 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
 
 // Column-major variant: every column has its own array, dtype and mode (the compare_sample_sets
 // output mixes float32 and float64 numpy-repr columns, compareSampleSets.py:252-270).
-extern "C" int sdice_write_columns(const char* path, const char* header, int64_t n, const char* names,
-                                   const int64_t* name_off, int32_t ncols, const void* const* cols,
-                                   const int32_t* dtypes, const int32_t* modes, int threads) try {
-    if (!path || !header || n < 0 || ncols < 0 || (n > 0 && (!names || !name_off)) || (ncols > 0 && (!cols || !dtypes || !modes))) {
+static int write_columns_impl(const char* path, const char* header, int64_t n, const char* names,
+                              const int64_t* name_off, int32_t ncols, const void* const* cols,
+                              const int32_t* dtypes, const int32_t* modes, const char* sfx, const int64_t* sfx_off,
+                              int threads) {
+    if (!path || !header || n < 0 || ncols < 0 || (n > 0 && (!names || !name_off)) || (ncols > 0 && (!cols || !dtypes || !modes)) ||
+        (sfx_off && !sfx && n > 0 && sfx_off[n] > 0)) {
         sdice_set_error("sdice_write_columns: bad arguments");
         return SDICE_ERR_ARG;
     }
@@ -259,6 +261,7 @@ extern "C" int sdice_write_columns(const char* path, const char* header, int64_t
                         else put_repr<double>(out, v);
                     }
                 }
+                if (sfx_off) out.append(sfx + sfx_off[r], (size_t)(sfx_off[r + 1] - sfx_off[r]));
                 out += '\n';
             }
         });
@@ -274,11 +277,34 @@ extern "C" int sdice_write_columns(const char* path, const char* header, int64_t
         return SDICE_ERR_ARG;
     }
     return SDICE_OK;
+}
+
+extern "C" int sdice_write_columns(const char* path, const char* header, int64_t n, const char* names,
+                                   const int64_t* name_off, int32_t ncols, const void* const* cols,
+                                   const int32_t* dtypes, const int32_t* modes, int threads) try {
+    return write_columns_impl(path, header, n, names, name_off, ncols, cols, dtypes, modes, nullptr, nullptr, threads);
 } catch (const std::exception& e) {
     sdice_set_error("sdice_write_columns: %s", e.what());
     return SDICE_ERR_NOMEM;
 } catch (...) {
     sdice_set_error("sdice_write_columns: unknown exception");
+    return SDICE_ERR_STATE;
+}
+
+// The same table with a ready-made text suffix per row (sfx[sfx_off[r] .. sfx_off[r+1]), written after the last
+// numeric column, before the newline): the gene / overlapping / transcript_id columns of an annotated
+// compare_sample_sets table (compareSampleSets.py:238-264).
+extern "C" int sdice_write_columns_sfx(const char* path, const char* header, int64_t n, const char* names,
+                                       const int64_t* name_off, int32_t ncols, const void* const* cols,
+                                       const int32_t* dtypes, const int32_t* modes, const char* sfx,
+                                       const int64_t* sfx_off, int threads) try {
+    if (!sfx_off) { sdice_set_error("sdice_write_columns_sfx: sfx_off is NULL"); return SDICE_ERR_ARG; }
+    return write_columns_impl(path, header, n, names, name_off, ncols, cols, dtypes, modes, sfx, sfx_off, threads);
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_write_columns_sfx: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_write_columns_sfx: unknown exception");
     return SDICE_ERR_STATE;
 }
 
@@ -340,6 +366,71 @@ extern "C" int sdice_write_clusters(const char* path, int64_t n, const char* nam
     return SDICE_ERR_NOMEM;
 } catch (...) {
     sdice_set_error("sdice_write_clusters: unknown exception");
+    return SDICE_ERR_STATE;
+}
+
+// `_junctions.bed` (SPLICEDICE.py:316-321): one line per junction row,
+// chrom<TAB>left<TAB>right<TAB>chrom:left-right:strand<TAB>0<TAB>strand
+extern "C" int sdice_write_junction_bed(const char* path, int64_t n, const char* chrom_names, const int64_t* chrom_off,
+                                        int32_t n_chrom, const int32_t* chrom, const int32_t* left, const int32_t* right,
+                                        const char* strand, int threads) try {
+    if (!path || n < 0 || n_chrom < 0 || (n > 0 && (!chrom_names || !chrom_off || !chrom || !left || !right || !strand))) {
+        sdice_set_error("sdice_write_junction_bed: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    FILE* fh = fopen(path, "wb");
+    if (!fh) {
+        sdice_set_error("sdice_write_junction_bed: cannot open %s", path);
+        return SDICE_ERR_ARG;
+    }
+    const int64_t block = 1 << 18;
+    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    std::vector<std::string> bufs;
+    for (int64_t r0 = 0; r0 < n; r0 += block) {
+        const int64_t nb = std::min(block, n - r0);
+        int used = nb < 4096 ? 1 : std::min(nthreads, 64);
+        if (used < 1) used = 1;
+        bufs.assign(used, std::string());
+        std::atomic<bool> bad{false};
+        parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
+            std::string& out = bufs[t];
+            char num[16];
+            for (int64_t r = r0 + a; r < r0 + b; ++r) {
+                const int32_t c = chrom[r];
+                if (c < 0 || c >= n_chrom) { bad = true; continue; }
+                const char* cn = chrom_names + chrom_off[c];
+                const size_t cl = (size_t)(chrom_off[c + 1] - chrom_off[c]);
+                const int ll = snprintf(num, sizeof num, "%d", left[r]);
+                const std::string ls(num, (size_t)ll);
+                const int rl = snprintf(num, sizeof num, "%d", right[r]);
+                const std::string rs(num, (size_t)rl);
+                out.append(cn, cl); out += '\t'; out += ls; out += '\t'; out += rs; out += '\t';
+                out.append(cn, cl); out += ':'; out += ls; out += '-'; out += rs; out += ':'; out += strand[r];
+                out += "\t0\t"; out += strand[r]; out += '\n';
+            }
+        });
+        if (bad) {
+            fclose(fh);
+            sdice_set_error("sdice_write_junction_bed: chromosome index out of range");
+            return SDICE_ERR_ARG;
+        }
+        for (auto& b : bufs)
+            if (!b.empty() && fwrite(b.data(), 1, b.size(), fh) != b.size()) {
+                fclose(fh);
+                sdice_set_error("sdice_write_junction_bed: short write to %s", path);
+                return SDICE_ERR_ARG;
+            }
+    }
+    if (fclose(fh) != 0) {
+        sdice_set_error("sdice_write_junction_bed: close failed for %s", path);
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_write_junction_bed: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_write_junction_bed: unknown exception");
     return SDICE_ERR_STATE;
 }
 

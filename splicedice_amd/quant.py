@@ -110,6 +110,7 @@ class Quant:
         for dst, src in zip(rows, junc):
             dst[row_of] = src                                  # row order (SPLICEDICE.py:96)
         self.rows = tuple(rows)
+        self.chrom_names = chrom_names
         self.junctions = [(chrom_names[c], int(l), int(r), textio.STRAND_SYM[s])
                           for c, l, r, s in zip(*(a.tolist() for a in self.rows))]
         self.names = [textio.junction_name(j) for j in self.junctions]
@@ -175,9 +176,7 @@ class Quant:
 
     # ------------------------------------------------------------------ writers (SPLICEDICE.py:316-370)
     def write_junction_bed(self):
-        with open(f"{self.outputPrefix}_junctions.bed", "w") as out:
-            for j, name in zip(self.junctions, self.names):
-                out.write(f"{j[0]}\t{j[1]}\t{j[2]}\t{name}\t0\t{j[3]}\n")
+        textio.write_junction_bed(f"{self.outputPrefix}_junctions.bed", self.chrom_names, *self.rows)
 
     def write_clusters(self):
         textio.write_clusters(f"{self.outputPrefix}_allClusters.tsv", self.names, self.row_ptr, self.col)

@@ -82,10 +82,11 @@ def write_table(path, header, names, data, mode, threads=0, append=False):
     _ffi.check(rc, "sdice_write_table")
 
 
-def write_columns(path, header, names, columns, modes, threads=0):
+def write_columns(path, header, names, columns, modes, threads=0, suffixes=None):
     """Like write_table for column-major data: `columns` is a list of 1-D arrays (float32 / float64
     / int32, one value per row), `modes` one of '.3f' | '.0f' | 'repr' per column
-    (sdice_write_columns)."""
+    (sdice_write_columns).  `suffixes`: one ready-made string per row, written after the last numeric
+    column (sdice_write_columns_sfx)."""
     import ctypes as C
     from . import _ffi
     lib = _ffi.load()
@@ -102,10 +103,45 @@ def write_columns(path, header, names, columns, modes, threads=0):
     ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
     dts = np.array([_DTYPE_CODE[c.dtype] for c in cols], dtype=np.int32)
     mds = np.array([_MODE_CODE[m] for m in modes], dtype=np.int32)
+    if suffixes is not None:
+        assert len(suffixes) == n
+        sb = [str(x).encode() for x in suffixes]
+        soff = np.zeros(n + 1, dtype=np.int64)
+        if n:
+            np.cumsum([len(b) for b in sb], out=soff[1:])
+        sblob = b"".join(sb)
+        rc = lib.sdice_write_columns_sfx(str(path).encode(), header.encode(), n, C.c_char_p(blob),
+                                         off.ctypes.data_as(C.c_void_p), len(cols), ptrs, dts.ctypes.data_as(C.c_void_p),
+                                         mds.ctypes.data_as(C.c_void_p), C.c_char_p(sblob), soff.ctypes.data_as(C.c_void_p),
+                                         int(threads))
+        _ffi.check(rc, "sdice_write_columns_sfx")
+        return
     rc = lib.sdice_write_columns(str(path).encode(), header.encode(), n, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
                                  len(cols), ptrs, dts.ctypes.data_as(C.c_void_p), mds.ctypes.data_as(C.c_void_p),
                                  int(threads))
     _ffi.check(rc, "sdice_write_columns")
+
+
+def interval_overlaps(ev_group, ev_a, ev_b, grp_ptr, lo, hi, threads=0):
+    """-> (ptr[n_events+1], idx): for every event the intervals of its group (ev_group, -1 = none) that contain
+    ev_a or ev_b, in interval order (sdice_interval_overlaps; compareSampleSets.py:246-252)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    g = np.ascontiguousarray(ev_group, dtype=np.int32)
+    a = np.ascontiguousarray(ev_a, dtype=np.int64)
+    b = np.ascontiguousarray(ev_b, dtype=np.int64)
+    gp = np.ascontiguousarray(grp_ptr, dtype=np.int64)
+    lo = np.ascontiguousarray(lo, dtype=np.int64)
+    hi = np.ascontiguousarray(hi, dtype=np.int64)
+    assert g.size == a.size == b.size and gp.size >= 1 and lo.size == hi.size == gp[-1]
+    ptr = np.zeros(g.size + 1, dtype=np.int64)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    args = (g.size, vp(g), vp(a), vp(b), gp.size - 1, vp(gp), vp(lo), vp(hi), vp(ptr))
+    _ffi.check(lib.sdice_interval_overlaps(*args, None, 0, int(threads)), "sdice_interval_overlaps")
+    idx = np.zeros(max(int(ptr[-1]), 1), dtype=np.int64)
+    _ffi.check(lib.sdice_interval_overlaps(*args, vp(idx), idx.size, int(threads)), "sdice_interval_overlaps")
+    return ptr, idx[: int(ptr[-1])]
 
 
 def write_clusters(path, names, row_ptr, col, threads=0):
@@ -125,6 +161,29 @@ def write_clusters(path, names, row_ptr, col, threads=0):
     rc = lib.sdice_write_clusters(str(path).encode(), n, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
                                   rp.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p), int(threads))
     _ffi.check(rc, "sdice_write_clusters")
+
+
+def write_junction_bed(path, chrom_names, chrom, left, right, strand, threads=0):
+    """`_junctions.bed` (SPLICEDICE.py:316-321) from the row-ordered junction arrays: chrom = index into
+    chrom_names, strand = index into STRAND_SYM (sdice_write_junction_bed)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    blobs = [str(c).encode() for c in chrom_names]
+    off = np.zeros(len(blobs) + 1, dtype=np.int64)
+    if blobs:
+        np.cumsum([len(b) for b in blobs], out=off[1:])
+    blob = b"".join(blobs)
+    ch = np.ascontiguousarray(chrom, dtype=np.int32)
+    lf = np.ascontiguousarray(left, dtype=np.int32)
+    rt = np.ascontiguousarray(right, dtype=np.int32)
+    sym = np.frombuffer("".join(STRAND_SYM).encode(), dtype=np.uint8)
+    st = np.ascontiguousarray(sym[np.asarray(strand, dtype=np.int64)]) if ch.size else np.zeros(0, dtype=np.uint8)
+    assert ch.size == lf.size == rt.size == st.size
+    rc = lib.sdice_write_junction_bed(str(path).encode(), ch.size, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
+                                      len(blobs), ch.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                                      rt.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), int(threads))
+    _ffi.check(rc, "sdice_write_junction_bed")
 
 
 def read_table_numeric(path, dtype=np.float32, threads=0):

@@ -67,6 +67,12 @@ int main(int argc, char** argv) {
         CHECK(sdice_write_clusters(pk.c_str(), n, names.data(), off.data(), rp.data(), col.data(), threads) == 0);
         col[3] = (int32_t)n + 5;                     // an out-of-range neighbour must be refused, not read
         CHECK(sdice_write_clusters(pk.c_str(), n, names.data(), off.data(), rp.data(), col.data(), threads) != 0);
+        // junction bed writer: three chromosome names, an out-of-range chromosome index must be refused
+        const std::string cn = "chr1chrXKI270728.1"; const int64_t co[4] = {0, 4, 8, 18};
+        std::vector<int32_t> ch(n), lf(n), rt(n); std::string sd((size_t)n, '+');
+        for (int64_t i = 0; i < n; ++i) { ch[i] = (int32_t)(i % 3); lf[i] = (int32_t)(i * 7); rt[i] = (int32_t)(i * 7 + 100 + i % 11); if (i % 2) sd[i] = '-'; }
+        CHECK(sdice_write_junction_bed(pk.c_str(), n, cn.data(), co, 3, ch.data(), lf.data(), rt.data(), sd.data(), threads) == 0);
+        if (n > 2) { ch[2] = 3; CHECK(sdice_write_junction_bed(pk.c_str(), n, cn.data(), co, 3, ch.data(), lf.data(), rt.data(), sd.data(), threads) != 0); }
     }
     // junction parser + lookup on every file given as path:type
     for (int a = 2; a < argc; ++a) {

@@ -356,3 +356,72 @@ def test_shard_plan_c_abi_equals_numpy_formulation():
             for frac in (0.02, 0.0, 0.5):
                 assert shard.shard_plan(row_ptr, col, world, frac) == _shard_plan_numpy(row_ptr, col, world, frac), (cr.size, world, frac)
     assert shard.shard_plan(np.zeros(1, np.int64), np.zeros(0, np.int32), 3) == [dict(own_lo=0, own_hi=0, ext_lo=0, ext_hi=0)] * 3
+
+
+def test_junction_bed_writer_matches_reference_file(golden_dir, tmp_path):
+    """sdice_write_junction_bed against a `_junctions.bed` the reference wrote (SPLICEDICE.py:316-321) and
+    against the format string on awkward names"""
+    from splicedice_amd import textio
+    want = open(os.path.join(golden_dir, "quant_c1", "expected_default", "out_junctions.bed")).read()
+    chrom_names, chrom, left, right, strand = [], [], [], [], []
+    for ln in want.splitlines():
+        c, l, r, _, _, s = ln.split("\t")
+        if c not in chrom_names:
+            chrom_names.append(c)
+        chrom.append(chrom_names.index(c)); left.append(int(l)); right.append(int(r)); strand.append("+-".index(s))
+    out = tmp_path / "j.bed"
+    textio.write_junction_bed(out, chrom_names, chrom, left, right, strand)
+    assert out.read_text() == want
+    rng = np.random.default_rng(4)
+    names = ["chr1", "HLA-A*01:01", "KI270728.1", "2"]
+    n = 30000                                            # several worker threads
+    chrom = rng.integers(0, 4, n); left = rng.integers(0, 2 ** 31 - 2, n); right = left + rng.integers(0, 2, n)
+    strand = rng.integers(0, 2, n)
+    textio.write_junction_bed(out, names, chrom, left, right, strand)
+    want = "".join(f"{names[c]}\t{l}\t{r}\t{names[c]}:{l}-{r}:{'+-'[s]}\t0\t{'+-'[s]}\n"
+                   for c, l, r, s in zip(chrom.tolist(), left.tolist(), right.tolist(), strand.tolist()))
+    assert out.read_text() == want
+    textio.write_junction_bed(out, names, [], [], [], [])
+    assert out.read_text() == ""
+    with pytest.raises(RuntimeError):
+        textio.write_junction_bed(out, names, [4], [1], [2], [0])
+
+
+def test_interval_overlaps_equals_the_reference_loop():
+    from splicedice_amd import textio
+    rng = np.random.default_rng(12)
+    n_groups = 5
+    sizes = [0, 1, 40, 300, 7]
+    grp_ptr = np.concatenate([[0], np.cumsum(sizes)])
+    lo = rng.integers(0, 10000, grp_ptr[-1]); hi = lo + rng.integers(0, 3000, grp_ptr[-1])
+    n = 20000
+    g = rng.integers(-1, n_groups, n); a = rng.integers(0, 13000, n); b = a + rng.integers(0, 500, n)
+    ptr, idx = textio.interval_overlaps(g, a, b, grp_ptr, lo, hi)
+    assert ptr[0] == 0 and ptr[-1] == idx.size
+    for e in rng.integers(0, n, 400).tolist() + [0, n - 1]:
+        want = [] if g[e] < 0 else [k for k in range(grp_ptr[g[e]], grp_ptr[g[e] + 1])
+                                     if (a[e] >= lo[k] and a[e] <= hi[k]) or (b[e] >= lo[k] and b[e] <= hi[k])]
+        assert idx[ptr[e]:ptr[e + 1]].tolist() == want
+    ptr, idx = textio.interval_overlaps([], [], [], [0], [], [])
+    assert ptr.tolist() == [0] and idx.size == 0
+
+
+@pytest.mark.parametrize("gtf,table,known", [("anno.gtf", "expected_out_gtf.tsv", False),
+                                              ("anno_hits.gtf", "expected_out_gtf_hits.tsv", True)])
+def test_annotation_columns_against_reference_table(golden_dir, tmp_path, gtf, table, known):
+    """gene / overlapping / transcript_id of the annotated compare_sample_sets table (compareSampleSets.py:238-264);
+    the second fixture (tests/golden/make_golden_annot.py) has exons bordering tested events: a junction of two
+    transcripts of one gene, one of two genes, genes on identical coordinates, the other strand"""
+    from splicedice_amd import compare_sample_sets as css, textio
+    d = os.path.join(golden_dir, "compare")
+    want = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(d, table))][1:]
+    names = [w[0] for w in want]
+    sfx = css.annotation_suffixes(names, os.path.join(d, gtf))
+    assert sfx == ["\t" + "\t".join(w[8:11]) for w in want]
+    assert any(w[9] for w in want) and any(w[8] != "nan" for w in want) == known
+    # and the suffix path of the column writer
+    out = tmp_path / "t.tsv"
+    x = np.arange(len(names), dtype=np.float64) / 7
+    textio.write_columns(out, "event\tx\tgene\toverlapping\ttranscript_id\n", names, [x], ["repr"], suffixes=sfx)
+    got = out.read_text().splitlines()
+    assert got[1:] == [f"{nm}\t{str(np.float64(v))}{s}" for nm, v, s in zip(names, x, sfx)]
