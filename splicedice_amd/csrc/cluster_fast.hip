@@ -77,6 +77,8 @@ struct FastArgs {
     uint32_t* bmax64;      // [ceil(n/64)] max right per 64 rows
     unsigned long long* tile_state;   // look-back granules of the neighbour kernel
     int32_t* row_of; int64_t* row_ptr; int32_t* col; int64_t col_cap;
+    int spb;               // sample keys per bucket
+    int sample_sort;       // buckets of 512..4096 keys: LDS-local sample sort (param cluster.sample_sort, default 1)
     int ablate;            // timing experiments only (param cluster.ablate): results are wrong when set
 };
 
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(256) splitter_kernel(FastArgs a) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= a.S) return;
     const uint32_t rk = a.rank[q];
-    if (rk != 0 && rk % SPB == 0) a.spl[rk / SPB - 1] = sample_key(a, q);      // slots 0 .. B-2
+    if (rk != 0 && rk % a.spb == 0) a.spl[rk / a.spb - 1] = sample_key(a, q);      // slots 0 .. B-2
 }
 
 // ------------------------------------------------------------------ 2. classify + scatter into slots
@@ -315,7 +317,174 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t* buf, int count, int P
     __syncthreads();
 }
 
-constexpr int SORT_T = 1024;
+constexpr int SORT_T_ = 1024;
+// ---- sorting a bucket's packed keys WITHOUT the workgroup-wide network: an LDS-local sample sort.
+// The network above costs ~66 dependent LDS round trips for a 2 048-key bucket, most of them behind a
+// workgroup barrier -- ~50 us per workgroup, and the whole grid is one round of workgroups, so that IS
+// the kernel's time.  Here: 256 regular samples ranked against each other by all threads (keys are
+// distinct: the slot index rides in the low bits), every 16th a splitter; each key finds its sub-bucket
+// (4 probes), one LDS atomic per (wave, sub-bucket) hands out offsets, a list of 16-bit positions per
+// sub-bucket goes to the unused upper half of the key buffer; then ONE WAVE per sub-bucket gathers its
+// keys and sorts them in registers (2 / 4 / 8 keys per lane, cross-lane steps by ds_bpermute, no LDS
+// storage, no barrier) and writes them back in order.  Four workgroup barriers instead of ~25.
+template <int K>
+__device__ __forceinline__ void wave_sort_u64(uint64_t (&key)[K], const int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64 * K; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j >= 1; j >>= 1) {
+            if (j >= K) {
+                const int lm = j / K;
+                const bool lower = (lane & lm) == 0;
+                const bool up = k2 >= 64 * K ? true : (lane & (k2 / K)) == 0;
+                const bool keep_min = lower == up;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(key[k] & 0xffffffffu), lm);
+                    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key[k] >> 32), lm);
+                    const uint64_t o = ((uint64_t)hi << 32) | lo;
+                    const bool take = keep_min ? o < key[k] : o > key[k];
+                    key[k] = take ? o : key[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int kp = k ^ j;
+                    if (kp > k) {
+                        bool up;
+                        if (k2 < K) up = (k & k2) == 0;
+                        else if (k2 >= 64 * K) up = true;
+                        else up = (lane & (k2 / K)) == 0;
+                        const bool sw = up ? key[kp] < key[k] : key[kp] > key[k];
+                        const uint64_t tk = key[k];
+                        key[k] = sw ? key[kp] : tk;
+                        key[kp] = sw ? tk : key[kp];
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr int SS_NB = 16;            // sub-buckets = waves of the workgroup
+constexpr int SS_MIN = 512, SS_MAX = 6400, SS_SUB_CAP = 1024;
+constexpr int SS_KPT = (SS_MAX + SORT_T_ - 1) / SORT_T_;      // keys per thread
+static_assert((8192 - SS_MAX) * 8 >= SS_MAX * 2 && (8192 - SS_MAX) * 8 >= 256 * 12, "scratch behind the keys must hold the lists / the sample");
+
+template <int K>
+__device__ __forceinline__ void ss_sort_sub(const uint64_t* kb, const unsigned short* list, int n, int lane, uint64_t (&key)[16]) {
+    uint64_t k_[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int p = k * 64 + lane;
+        k_[k] = p < n ? kb[list[p]] : ~0ull;
+    }
+    wave_sort_u64<K>(k_, lane);
+#pragma unroll
+    for (int k = 0; k < K; ++k) key[k] = k_[k];
+}
+
+// true: kb[0..count) is sorted.  false (a sub-bucket above SS_SUB_CAP keys): kb is untouched.
+// The 8192-key buffer holds `count` keys; what lies behind them is scratch: first the sample and its ranks,
+// then the per-sub-bucket lists of 16-bit key positions.
+__device__ __forceinline__ bool lds_sample_sort(uint64_t* kb, int count, int t) {
+    __shared__ unsigned s_cnt[SS_NB], s_base[SS_NB + 1], s_max;
+    __shared__ uint64_t s_spl[SS_NB];
+    const int lane = t & 63, w = t >> 6;
+    uint64_t* smp = kb + count;
+    const int ns = count <= 2048 ? 128 : 256;                           // 8 or 16 samples per sub-bucket
+    const int per = ns / SS_NB;
+    unsigned* rnk = reinterpret_cast<unsigned*>(smp + ns);
+    unsigned short* list = reinterpret_cast<unsigned short*>(kb + count);    // (after the sample is done with)
+    __syncthreads();
+    if (t < ns) { smp[t] = kb[(int)((int64_t)t * count / ns)]; rnk[t] = 0u; }
+    if (t < SS_NB) s_cnt[t] = 0u;
+    __syncthreads();
+    {
+        // every thread ranks one sample against one chunk of the sample (keys are distinct)
+        const int i = t & (ns - 1), chunk = SORT_T_ / ns, c = t / ns, len = ns / chunk;
+        const uint64_t me = smp[i];
+        unsigned below = 0;
+        for (int j = c * len; j < c * len + len; ++j) below += smp[j] < me ? 1u : 0u;
+        atomicAdd(&rnk[i], below);
+    }
+    __syncthreads();
+    if (t < ns) {
+        const unsigned r = rnk[t];
+        if (r > 0 && r % (unsigned)per == 0) s_spl[r / (unsigned)per - 1] = smp[t];
+    }
+    __syncthreads();
+    // sub-bucket and offset of this thread's keys, packed (offset << 4 | sub-bucket), -1 = none
+    int where[SS_KPT];
+#pragma unroll
+    for (int q = 0; q < SS_KPT; ++q) {
+        const int i = q * SORT_T_ + t;
+        const bool act = i < count;
+        int b = 0;
+        if (act) {
+            const uint64_t key = kb[i];
+            int lo = 0, hi = SS_NB - 1;                                 // number of splitters <= key
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const bool le = s_spl[mid] <= key;
+                lo = le ? mid + 1 : lo;
+                hi = le ? hi : mid;
+            }
+            b = lo;
+        }
+        unsigned long long m = __ballot(act);
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) {
+            const unsigned long long bb = __ballot((b >> bit) & 1);
+            m &= ((b >> bit) & 1) ? bb : ~bb;
+        }
+        unsigned basew = 0;
+        if (act) {
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) basew = atomicAdd(&s_cnt[b], (unsigned)__popcll(m));
+            basew = (unsigned)__shfl((int)basew, leader);
+        }
+        where[q] = act ? (int)(((basew + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) << 4) | (unsigned)b) : -1;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const unsigned c = lane < SS_NB ? s_cnt[lane] : 0u;
+        unsigned x = c, mx = c;
+#pragma unroll
+        for (int o = 1; o < SS_NB; o <<= 1) {
+            const unsigned y = (unsigned)__shfl_up((int)x, o);
+            if (lane >= o) x += y;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if (lane < SS_NB) s_base[lane + 1] = x;
+        if (lane == 0) { s_base[0] = 0u; s_max = mx; }
+    }
+    __syncthreads();
+    if (s_max > (unsigned)SS_SUB_CAP) return false;
+#pragma unroll
+    for (int q = 0; q < SS_KPT; ++q)
+        if (where[q] >= 0) list[s_base[where[q] & 15] + (unsigned)(where[q] >> 4)] = (unsigned short)(q * SORT_T_ + t);
+    __syncthreads();
+    const int n = (int)s_cnt[w];
+    const unsigned base = s_base[w];
+    uint64_t key[16];
+    const int K = n <= 128 ? 2 : n <= 256 ? 4 : n <= 512 ? 8 : 16;
+    if (K == 2) ss_sort_sub<2>(kb, list + base, n, lane, key);
+    else if (K == 4) ss_sort_sub<4>(kb, list + base, n, lane, key);
+    else if (K == 8) ss_sort_sub<8>(kb, list + base, n, lane, key);
+    else ss_sort_sub<16>(kb, list + base, n, lane, key);
+    __syncthreads();                                                    // every wave holds its keys: kb may be overwritten
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int p = lane * K + k;
+        if (k < K && p < n) kb[base + p] = key[k];
+    }
+    __syncthreads();
+    return true;
+}
+
+constexpr int SORT_T = SORT_T_;
 constexpr int SORT_WAVES = SORT_T / 64;
 constexpr int RDX_CAP = 8192;                    // packed 64-bit keys a bucket may hold in LDS
 constexpr int RDX_IDX_BITS = 13;                 // slot index of an element rides in the low bits of its key
@@ -414,7 +583,10 @@ __global__ void __launch_bounds__(SORT_T, 8) bucket_sort_kernel(FastArgs a) {   
         //  and a 8192-counter scan each -- against ~1 us per ten steps of this network.)
         int P = 1;
         while (P < count) P <<= 1;
-        if (P > 1 && !SD_ABL(a, 1)) bitonic_sort_u64(kb0, count, P, t, SORT_T); else __syncthreads();
+        bool sorted_already = false;
+        if (a.sample_sort && count >= SS_MIN && count <= SS_MAX && !SD_ABL(a, 1)) sorted_already = lds_sample_sort(kb0, count, t);
+        if (sorted_already) {}
+        else if (P > 1 && !SD_ABL(a, 1)) bitonic_sort_u64(kb0, count, P, t, SORT_T); else __syncthreads();
         const uint64_t* sorted = kb0;
         for (int i = t; i + 1 < count; i += SORT_T)
             if ((sorted[i] >> RDX_IDX_BITS) == (sorted[i + 1] >> RDX_IDX_BITS)) dup = 1;
@@ -779,16 +951,22 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
               const int8_t* d_strand, int32_t* d_row_of, int64_t* d_row_ptr, FastPlan& pl) {
     FastArgs& a = pl.a;
     a.chrom = d_chrom; a.left = d_left; a.right = d_right; a.strand = d_strand; a.n = n;
-    int64_t B = sd_ceil_div(n, BUCKET_MEAN);
+    int64_t bucket_mean = ctx->param("cluster.bucket_mean", BUCKET_MEAN);
+    if (bucket_mean < 256 || bucket_mean > BUCKET_MEAN) bucket_mean = BUCKET_MEAN;
+    int64_t B = sd_ceil_div(n, bucket_mean);
     if (B < 1) B = 1;
+    if (B > MAX_BUCKETS) B = MAX_BUCKETS;
     a.B = (int)B;
-    a.S = B > 1 ? (int)(B * SPB) : 0;
+    a.spb = (int)ctx->param("cluster.spb", SPB);
+    if (a.spb < 2 || a.spb > 64) a.spb = SPB;
+    a.S = B > 1 ? (int)(B * a.spb) : 0;
     const int64_t mean = sd_ceil_div(n, B);
     a.slot_cap = B > 1 ? (mean * SLOT_FACTOR < n ? mean * SLOT_FACTOR : n) : n;
     int64_t lds_cap = ctx->param("cluster.lds_cap", 8192);      // (test knob: 0 = default; small values force the HBM sort)
     if (lds_cap <= 0 || lds_cap > 8192) lds_cap = 8192;
     if (lds_cap < 2) lds_cap = 2;
     a.lds_cap = (int)lds_cap;
+    a.sample_sort = ctx->param("cluster.sample_sort", 1) != 0;
     pl.n_tiles = (int)sd_ceil_div(n, NB_T);
     const size_t nb64 = (size_t)sd_ceil_div(n, 64) + 2;
     // The status block is a small persistent allocation of the context (an asynchronous call is

@@ -16,7 +16,8 @@ d = [ctx.to_device(x) for x in junc]
 d_row_of, d_rp = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
 ctx.cluster_dev(*d, d_row_of, d_rp)
 for m in masks:
-    ctx.set_param("cluster.big_tiles", 1 if m < 0 else 0)
+    ctx.set_param("cluster.sample_sort", 0 if m < 0 else 1)      # negative mask: the workgroup-wide network instead
+    tag = "network" if m < 0 else "sample-sort"
     m = abs(m) if m != -9999 else 0
     ctx.set_param("cluster.ablate", m)
     ctx.prof_enable(0)
@@ -43,5 +44,6 @@ for m in masks:
     except SdiceError:
         pass
     rep = {k: round(v[1] / 5 * 1000, 1) for k, v in ctx.prof_report().items()}
-    print("ablate", m, "async %.3f ms;" % wall, json.dumps(rep), "sum %.1f us" % sum(rep.values()), flush=True)
+    print(tag, "ablate", m, "async %.3f ms;" % wall, json.dumps(rep), "sum %.1f us" % sum(rep.values()), flush=True)
 ctx.set_param("cluster.ablate", 0)
+ctx.set_param("cluster.sample_sort", 1)
