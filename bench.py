@@ -56,6 +56,7 @@ from splicedice_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: measured float4-copy ceiling (SURVEY 8(d) asks for both denominators)
+F64_WAVE_INSTS_PER_S = 5.25e11   # measured f64 FMA issue rate (tools/mb/microbench.hip: 33.6e12 lane-FMAs/s over 1024 SIMDs)
 
 
 def parse_args():
@@ -600,6 +601,20 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
                 "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": wl.alg_bytes,
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": traffic[1] if traffic else "no PMC pass committed for this shape"}
+    if wl.key == "pairwise" and launches:
+        # the Fisher kernel is f64-VALU bound: achieved VALU issue against the f64 issue rate of the chip
+        # (tools/mb/microbench.hip: 33.6e12 f64 FMA lane-operations/s = 5.25e11 wave64 instructions/s),
+        # instruction and active-lane counts from the committed SQ counter passes of this shape
+        try:
+            with open(os.path.join(REPO, "profiles", "pairwise_valu.json")) as fh:
+                pv = json.load(fh)
+            if pv["n"] == wl.n and pv["s"] == wl.s:
+                rate = pv["SQ_INSTS_VALU_per_launch"] / (avg_ms * 1e-3)
+                roofline["valu_f64"] = {"achieved": rate, "peak": F64_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s",
+                                        "frac": rate / F64_WAVE_INSTS_PER_S, "active_lanes_of_64": pv["active_lanes_of_64"],
+                                        "source": pv["source"]}
+        except (OSError, ValueError, KeyError):
+            pass
     v = None
     if verify:
         ok, checked = wl.verify()

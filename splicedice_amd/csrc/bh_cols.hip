@@ -396,10 +396,18 @@ __device__ __forceinline__ BucketRef bucket_ref(const BhsArgs& a, int64_t g) {
 // buckets of up to 256 values (nearly all of them): 4 keys per lane, ~40 VGPRs, 8 waves per SIMD.
 // Larger buckets go to a work list for bhs_bucket_big_kernel (whose 16-keys-per-lane network needs
 // 150 VGPRs: in one kernel it held every wave to 3 per SIMD and the loads' latency was not hidden).
-__global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int64_t n_buckets) {
+// Workgroups are dealt round-robin over the 8 XCDs and each XCD has its own L2: all buckets of one segment
+// go to workgroups of ONE XCD (segment mod 8), so that the scattered 8-byte results of a segment -- every
+// cache line of its 200 KB gets its 16 values from 16 different buckets -- meet in one L2 and leave it as
+// full lines.  (With buckets dealt over all XCDs every L2 wrote its own partial lines: 26.7 GB of write
+// traffic for 5 GB of results.)
+__global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int blocks_per_seg) {
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_buckets) return;
+    const int64_t k = (int64_t)(blockIdx.x >> 3);
+    const int64_t seg_x = (k / blocks_per_seg) * 8 + (blockIdx.x & 7);
+    const int b_x = (int)(k % blocks_per_seg) * 4 + (int)(threadIdx.x >> 6);
+    if (seg_x >= a.segs || b_x >= a.B) return;
+    const int64_t g = seg_x * a.B + b_x;
     const BucketRef r = bucket_ref(a, g);
     if (r.n_b <= 256 && r.n_b <= a.reg_cap) {
         bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
@@ -553,8 +561,10 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     const int64_t n_buckets = segs * B;
     SD_ARG(sd_ceil_div(n_buckets, (int64_t)4) < ((int64_t)1 << 31), "bh: too many buckets");
     SD_HIP(hipMemsetAsync(a.big_count, 0, 8, ctx->stream));
-    SD_LAUNCH(ctx, "bhs_bucket_kernel", bhs_bucket_kernel, dim3((unsigned)sd_ceil_div(n_buckets, (int64_t)4)), dim3(256), 0, a,
-              n_buckets);
+    const int blocks_per_seg = (int)sd_ceil_div((int64_t)B, (int64_t)4);
+    const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * blocks_per_seg;
+    SD_ARG(bucket_blocks < ((int64_t)1 << 31), "bh: too many buckets");
+    SD_LAUNCH(ctx, "bhs_bucket_kernel", bhs_bucket_kernel, dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
     SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel,
               dim3((unsigned)std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4)), dim3(256), 0, a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);

@@ -25,4 +25,8 @@ for C in SQ_INSTS_VALU SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_W
   echo "pmc quant $C"
   rocprofv3 --pmc $C --output-format csv -d $OUT/quant_sq_$C -- python3 bench.py --workload quant --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-also > /dev/null 2> $OUT/quant_sq_$C.err
 done
+for C in SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU; do
+  echo "pmc pairwise $C"
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pairwise_sq_$C -- python3 bench.py --workload pairwise --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-also > /dev/null 2> $OUT/pairwise_sq_$C.err
+done
 python3 tools/summarise_profiles.py $OUT $R

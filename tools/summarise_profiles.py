@@ -6,12 +6,18 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 os.makedirs(dst, exist_ok=True)
 
 
+def newest(pattern):
+    """the most recent file matching the pattern (gpurun merges a round's repeated runs into one directory)"""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
 for wl in ("quant", "compare", "pairwise", "e2e", "quant2m500"):
-    files = glob.glob(os.path.join(src, f"{wl}_trace", "*", "*_kernel_stats.csv"))
+    files = newest(os.path.join(src, f"{wl}_trace", "*", "*_kernel_stats.csv"))
     if not files:
         continue
     rows = list(csv.DictReader(open(files[0])))
@@ -35,7 +41,7 @@ records = []
 for wl, (dom, n, s) in DOMINANT.items():
     traffic = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = glob.glob(os.path.join(src, f"{wl}_pmc_{cname}", "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(src, f"{wl}_pmc_{cname}", "*", "*_counter_collection.csv"))
         if not files:
             continue
         agg = collections.defaultdict(list)
@@ -63,7 +69,7 @@ if records:
 sq = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(src, "quant_sq_*"))):
     cname = os.path.basename(d)[len("quant_sq_"):]
-    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(d, "*", "*_counter_collection.csv"))
     if not files:
         continue
     agg = collections.defaultdict(list)
@@ -79,4 +85,20 @@ if sq:
         out.writerow(["kernel"] + [f"{c}_per_launch" for c in names])
         for k in sorted(sq):
             out.writerow([k] + [f"{sq[k].get(c, float('nan')):.0f}" for c in names])
+# VALU issue of the Fisher kernel (f64-VALU bound): instructions and active lanes per launch
+pw = {}
+for cname in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"):
+    files = newest(os.path.join(src, f"pairwise_sq_{cname}", "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+            if r["Counter_Name"] == cname and short(r["Kernel_Name"]).startswith("fisher_pairs_kernel")]
+    if vals:
+        pw[cname + "_per_launch"] = sum(vals) / len(vals)
+if len(pw) == 2:
+    pw["kernel"] = "fisher_pairs_kernel"
+    pw["n"], pw["s"] = 25000, 200
+    pw["active_lanes_of_64"] = pw["SQ_THREAD_CYCLES_VALU_per_launch"] / pw["SQ_INSTS_VALU_per_launch"]
+    pw["source"] = f"rocprofv3 --pmc passes of `bench.py --workload pairwise` ({tag}), one counter per run"
+    json.dump(pw, open(os.path.join(dst, "pairwise_valu.json"), "w"), indent=1)
 print("profiles written:", sorted(os.listdir(dst)))
