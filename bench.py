@@ -17,12 +17,13 @@ Workloads (BASELINE.json configs):
   e2e     (config 5 per-GPU shard)  : 625k junctions x 1000 samples; step = cluster + PS + quantise
           + rank-sum (500 v 500) + [RCCL all-gather of p-values at N>1] + BH; metric = PS entries/s.
 
-Multi-GPU (quant): ONE dataset -- the N = 1 junction set -- is cut into N row ranges at chromosome
-boundaries (zero halo) and every rank clusters + quantifies its own range: total work fixed, "scaling":
-"strong".  No data-path collective is needed inside a step; the all-gather of the PS shards that the
-north star names is timed after the loop and reported in "ps_allgather" beside the design that leaves
-the shards in their owners' HBM.  --weak gives every rank an independently generated shard instead
-(per-GPU work fixed).  torch.distributed (gloo) is the control plane only (barrier, max / sum over
+Multi-GPU (quant): ONE dataset of N x 1 M junctions is cut into N row ranges at chromosome boundaries
+(zero halo; the ranges differ by a fraction of a per cent) and every rank clusters + quantifies its own
+range: per-GPU work fixed as N grows, "scaling": "weak" -- but over one junction set and real cuts, not N
+independent copies.  --strong keeps the TOTAL fixed instead (the N = 1 dataset cut into N ranges).  No
+data-path collective is needed inside a step; the all-gather of the PS shards that the north star names is
+timed after the loop and reported in "ps_allgather" beside the design that leaves the shards in their
+owners' HBM.  torch.distributed (gloo) is the control plane only (barrier, max / sum over
 ranks, the 128-byte RCCL id); the collectives are the library's own RCCL calls.
 
 The timed region is bracketed by barrier + device sync on both sides; rank 0 prints the
@@ -72,9 +73,10 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="junctions in the CPU-baseline sample")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under 'also'")
-    ap.add_argument("--weak", action="store_true",
-                    help="N>1, quant: one independently generated shard per rank (per-GPU work fixed) instead of the "
-                         "default: ONE dataset cut into N row ranges (total work fixed)")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1, quant: keep the TOTAL work fixed (the N = 1 dataset cut into N row ranges) instead of the "
+                         "default: one dataset of N x the per-GPU size (per-GPU work fixed)")
+    ap.add_argument("--weak", action="store_true", help="(the default at N>1; kept for old command lines)")
     return ap.parse_args()
 
 
@@ -221,16 +223,17 @@ class QuantWorkload:
                           f"(Python loops + numpy as the reference), {dt:.1f} s"}
 
 
-class StrongQuantWorkload(QuantWorkload):
-    """N > 1 (default): ONE dataset -- the N = 1 junction set -- cut into N row ranges at chromosome
-    boundaries (contiguous chromosome ranges with near-equal junction counts; rows are in (chrom, ...)
-    order, so no overlap edge crosses a cut: zero halo).  Every rank clusters and quantifies its own
-    range; the total work is fixed as N grows (strong scaling)."""
+class ShardedQuantWorkload(QuantWorkload):
+    """N > 1: ONE junction set cut into N row ranges at chromosome boundaries (contiguous chromosome ranges
+    with near-equal junction counts; rows are in (chrom, ...) order, so no overlap edge crosses a cut: zero
+    halo).  Every rank clusters and quantifies its own range.  Default: the set has N x the per-GPU size
+    (per-GPU work fixed: weak scaling); `strong`: the N = 1 set (total work fixed)."""
     name = "quant: cluster + PS, one dataset sharded over the ranks"
 
-    def __init__(self, ctx, rank, world, n, s):
+    def __init__(self, ctx, rank, world, n, s, strong=False):
         self.ctx, self.s = ctx, s or 100
-        self.n_total = n or 1_000_000
+        self.strong = strong
+        self.n_total = (n or 1_000_000) * (1 if strong else world)
         s = self.s
         t = time.time()
         cr, l, r, st = synth.make_junctions(self.n_total, 2)          # the N = 1 dataset, identical on every rank
@@ -256,8 +259,9 @@ class StrongQuantWorkload(QuantWorkload):
 
     def describe(self):
         d = super().describe()
-        d["workload"] = (f"quant {self.n_total} junctions x {self.s} samples in total (BASELINE config 2 dataset), cut at "
-                         f"chromosome boundaries into {self.world} row ranges, cluster+PS on each")
+        d["workload"] = (f"quant {self.n_total} junctions x {self.s} samples in total "
+                         f"({'the BASELINE config 2 dataset' if self.strong else 'one BASELINE config 2 dataset per GPU'}), "
+                         f"one junction set cut at chromosome boundaries into {self.world} row ranges, cluster+PS on each")
         d["junctions_total"] = self.n_total
         d["rows_per_rank"] = [b[3] - b[2] for b in self.ranges]
         return d
@@ -646,9 +650,10 @@ def main():
     # flow on a one-GPU box -- RCCL then refuses the duplicate GPU and "allgather" reports it)
     forced = os.environ.get("SDICE_BENCH_DEVICE")
     ctx = Context(int(forced) if forced is not None else (dist.local_rank if args.gpus > 1 else 0))
-    strong = args.gpus > 1 and args.workload == "quant" and not args.weak
-    if strong:
-        wl = StrongQuantWorkload(ctx, dist.rank, args.gpus, args.n, args.s)
+    sharded = args.gpus > 1 and args.workload == "quant"
+    strong = sharded and args.strong
+    if sharded:
+        wl = ShardedQuantWorkload(ctx, dist.rank, args.gpus, args.n, args.s, strong=strong)
     else:
         wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
     wl.key = args.workload
@@ -659,12 +664,12 @@ def main():
     failed = bool(verify and not verify["ok"])
 
     ps_allgather = None
-    if strong:
+    if sharded:
         ps_allgather = wl.ps_allgather(dist)      # reported, never hidden: the timed steps above contain no collective
         dist.barrier()
 
     allgather = None
-    if args.gpus > 1 and not strong and not getattr(wl, "needs_comm", False):
+    if args.gpus > 1 and not sharded and not getattr(wl, "needs_comm", False):
         # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction); every rank
         # goes through the same control-plane calls whatever fails where
         err = None
