@@ -348,6 +348,8 @@ __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restri
 //     T[key] in original order, medians are T[key] of the middle keys.
 // A row holding any value that is not exactly T[k] is marked RS_REDO and left to ranksum_wave_kernel.
 constexpr unsigned char RS_REDO_Q = 0xFF;       // (same mark as RS_REDO below)
+constexpr int RSQ_G2 = 64;                      // u16 offset of group 2 inside a staged row
+constexpr int RSQ_STRIDE = 130;                 // u16 per staged row: 65 dwords
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
@@ -425,6 +427,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             const bool act0 = lane < nsel, act1 = lane + 64 < nsel;
             const int sel0 = act0 ? selL[lane] : 0;
             const int sel1 = act1 ? selL[lane + 64] : 0;
+            // group 1 at the start of the row, group 2 at u16 offset 64: with a row pitch of 65 dwords the 32 rows x 2
+            // groups of a wave sit in 64 different banks (r and r + 32) whenever the lanes read the same element
+            // index -- the packed layout (group 2 right behind group 1, odd pitch) lost 47 % of its LDS cycles to
+            // bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+            const int pos0 = lane < n1 ? lane : RSQ_G2 + lane - n1;
+            const int pos1 = lane + 64 < n1 ? lane + 64 : RSQ_G2 + lane + 64 - n1;
             constexpr int RB = 16;
             for (int r0 = 0; r0 < 32; r0 += RB) {
                 float x0[RB], x1[RB];
@@ -445,8 +453,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const bool nan0 = !(a0 == a0) || !live, nan1 = !(a1 == a1) || !live;
                     const bool bad0 = act0 && !nan0 && T[k0] != a0, bad1 = act1 && !nan1 && T[k1] != a1;
                     if (__ballot(bad0 || bad1)) redo_rows |= 1u << r;
-                    if (act0) tile[r * stride + lane] = nan0 ? (unsigned short)0xFFFF : (unsigned short)k0;
-                    if (act1) tile[r * stride + lane + 64] = nan1 ? (unsigned short)0xFFFF : (unsigned short)k1;
+                    if (act0) tile[r * stride + pos0] = nan0 ? (unsigned short)0xFFFF : (unsigned short)k0;
+                    if (act1) tile[r * stride + pos1] = nan1 ? (unsigned short)0xFFFF : (unsigned short)k1;
                 }
             }
         }
@@ -454,7 +462,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         __builtin_amdgcn_wave_barrier();
         const int r = lane >> 1, grp = lane & 1;
         unsigned short* row = tile + r * stride;
-        unsigned short* grow = row + (grp ? n1 : 0);
+        unsigned short* grow = row + (grp ? RSQ_G2 : 0);
         const int cnt = grp ? n2 : n1;
         // ---- compaction (NaNs dropped, order kept) through LDS, then the keys of this group in registers
         int nv = 0;
@@ -504,34 +512,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             if (a < cnt) grow[a] = (unsigned short)(key[a] & 0xffffu);
             if (a + NR < cnt) grow[a + NR] = (unsigned short)(key[a] >> 16);
         }
+        grow[cnt] = (unsigned short)0xFFFF;      // sentinel behind the group (n1 <= 63: still inside its 64 slots)
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();          // the partner's sorted group is in LDS
         const int nv_other = __shfl_xor(nv, 1);
         const int nv1 = grp ? nv_other : nv, nv2 = grp ? nv : nv_other;
         const bool tested = nv1 >= 3 && nv2 >= 3;
         const unsigned short* A = row;
-        const unsigned short* B = row + n1;
+        const unsigned short* B = row + RSQ_G2;
         float med = 0.f;
         int part = 0;
         if (tested) {
             const unsigned short* G = grp ? B : A;
             const int h = nv >> 1;
             med = (nv & 1) ? T[G[h]] : (T[G[h - 1]] + T[G[h]]) / 2.0f;      // np.median on float32
-            int i = 0, j = 0;
+            // one merge walk; positions nv1 of A and nv2 of B hold 0xFFFF (the sorted padding or the sentinel), so an
+            // exhausted side loses every comparison and no index has to be checked or clamped.  The even lane
+            // counts "b <= a" (upper bounds), the odd lane "b < a": b goes first when b < a + adj.
+            const unsigned adj = grp ? 0u : 1u;
+            int jb = RSQ_G2;                          // row index of the next B element
             unsigned av = A[0], bv = B[0];
             const int steps = nv1 + nv2;
             for (int t = 0; t < steps; ++t) {
-                const bool before = grp ? (bv < av) : (bv <= av);
-                const bool take_b = j < nv2 && (i >= nv1 || before);
-                if (take_b) {
-                    ++j;
-                    bv = B[j < nv2 ? j : nv2 - 1];
-                } else {
-                    part += j;
-                    ++i;
-                    av = A[i < nv1 ? i : nv1 - 1];
-                }
+                const bool take_b = bv < av + adj;
+                part += take_b ? 0 : jb;              // (+ 64 per A element: taken off below)
+                jb += take_b ? 1 : 0;
+                const int i = t + 1 + RSQ_G2 - jb;    // A elements taken so far
+                const unsigned nx = row[take_b ? jb : i];
+                av = take_b ? av : nx;
+                bv = take_b ? nx : bv;
             }
+            part -= RSQ_G2 * nv1;
         }
         const int u2 = part + __shfl_xor(part, 1);
         const float med_other = __shfl_xor(med, 1);
@@ -1249,7 +1260,7 @@ int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
 template <int P>
 int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, const int32_t* g1, int n1,
                  const int32_t* g2, int n2, RsOut o) {
-    const int stride = (n1 + n2) | 1;                      // u16 units
+    const int stride = RSQ_STRIDE;                         // u16 units (n1, n2 <= 64)
     const int waves = 4;
     const int nsel = n1 + n2;
     const size_t lds = (size_t)1008 * 4 + (size_t)((nsel + 1) & ~1) * 4 + (size_t)waves * 32 * stride * 2;
@@ -1309,7 +1320,7 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
         SD_HIP(hipMemcpyAsync(gsel, d_g1, (size_t)n1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         SD_HIP(hipMemcpyAsync(gsel + n1, d_g2, (size_t)n2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         const int big = n1 > n2 ? n1 : n2;
-        if (variant == 0 && big > 16) {     // auto, groups of 17..64: the lane-pair kernel on 16-bit keys
+        if (variant == 0 && big > 16 && n1 <= 63) {     // auto, groups of 17..64 (group 1 <= 63: its sentinel slot): the lane-pair kernel on 16-bit keys
             if (big <= 32) return launch_pairq<32>(ctx, d_ps, n, s, gsel, d_g1, n1, d_g2, n2, o);
             return launch_pairq<64>(ctx, d_ps, n, s, gsel, d_g1, n1, d_g2, n2, o);
         }
