@@ -406,6 +406,24 @@ def test_fisher_pairs_vs_scipy(ctx, n, s, mean):
     np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
 
 
+def test_fisher_pairs_long_walks_and_sparse_rows(ctx):
+    """the pair kernel's state machine on walks of hundreds of steps (counts in the thousands: the products P, Q, S are
+    rescaled every few steps, the negligible-tail cut ends the walks) and on sparse rows (most pairs have a zero margin
+    and never enter a walk; one-sided walks when a sits on the edge of the support)"""
+    rng = np.random.default_rng(99)
+    s = 9
+    incl = rng.poisson(rng.choice([2500.0, 3000.0, 3300.0], size=(3, s))).astype(np.int32)
+    excl = rng.poisson(rng.choice([9000.0, 12000.0], size=(3, s))).astype(np.int64)
+    sparse_i = (rng.random((40, s)) < 0.25) * rng.integers(1, 30, size=(40, s))
+    sparse_e = (rng.random((40, s)) < 0.5) * rng.integers(1, 60, size=(40, s))
+    incl = np.vstack([incl, sparse_i.astype(np.int32)])
+    excl = np.vstack([excl, sparse_e.astype(np.int64)])
+    want = O.fisher_pairs(incl, excl)
+    got = ctx.fisher_pairs(incl, excl)
+    assert (want[3:] == 1.0).mean() > 0.3 and (want[:3] < 1e-3).any()        # the fixture exercises both
+    np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
+
+
 # ------------------------------------------------------------------------------ BH
 @pytest.mark.parametrize("m", [1, 2, 255, 256, 257, 5000, 100000])
 def test_bh_vs_oracle(ctx, m):

@@ -21,6 +21,12 @@ for WL in quant compare pairwise; do
     rocprofv3 --pmc $C --output-format csv -d $OUT/${WL}_pmc_$C -- python3 bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-verify --no-also > /dev/null 2> $OUT/${WL}_pmc_$C.err
   done
 done
+for C in FETCH_SIZE WRITE_SIZE; do
+  echo "pmc quant2m500 $C"
+  rocprofv3 --pmc $C --output-format csv -d $OUT/quant2m500_pmc_$C -- python3 bench.py --workload quant --junctions 2000000 --samples 500 --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-also > /dev/null 2> $OUT/quant2m500_pmc_$C.err
+  echo "pmc e2e $C"
+  rocprofv3 --pmc $C --output-format csv -d $OUT/e2e_pmc_$C -- python3 bench.py --workload e2e --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-also > /dev/null 2> $OUT/e2e_pmc_$C.err
+done
 for C in SQ_INSTS_VALU SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU; do
   echo "pmc quant $C"
   rocprofv3 --pmc $C --output-format csv -d $OUT/quant_sq_$C -- python3 bench.py --workload quant --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-also > /dev/null 2> $OUT/quant_sq_$C.err

@@ -35,10 +35,11 @@ for wl in ("quant", "compare", "pairwise", "e2e", "quant2m500"):
 # HBM traffic of every kernel from the two PMC passes.  MI355X_MICROARCH.md (HBM section): both
 # counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream
 # (x2), WRITE_SIZE is exact.
-DOMINANT = {"quant": ("ps_tile_kernel", 1000000, 100), "compare": ("ranksum_pair", 1000000, 100),
-            "pairwise": ("fisher_pairs_kernel", 25000, 200)}
+DOMINANT = [("quant", "quant", "ps_tile_kernel", 1000000, 100), ("compare", "compare", "ranksum_pair", 1000000, 100),
+            ("pairwise", "pairwise", "fisher_pairs_kernel", 25000, 200), ("quant2m500", "quant", "ps_tile_kernel", 2000000, 500),
+            ("e2e", "e2e", "ranksum_count_kernel", 625000, 1000)]
 records = []
-for wl, (dom, n, s) in DOMINANT.items():
+for wl, wl_key, dom, n, s in DOMINANT:
     traffic = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         files = newest(os.path.join(src, f"{wl}_pmc_{cname}", "*", "*_counter_collection.csv"))
@@ -60,7 +61,7 @@ for wl, (dom, n, s) in DOMINANT.items():
             out.writerow([k, f"{f:.1f}", f"{w:.1f}", f"{(2 * f + w) * 1024:.0f}"])
     hit = [v for k, v in traffic.items() if k.startswith(dom)]
     if hit:
-        records.append({"workload": wl, "n": n, "s": s, "kernel": [k for k in traffic if k.startswith(dom)][0],
+        records.append({"workload": wl_key, "n": n, "s": s, "kernel": [k for k in traffic if k.startswith(dom)][0],
                         "hbm_bytes_per_launch": (2 * hit[0].get("FETCH_SIZE", 0) + hit[0].get("WRITE_SIZE", 0)) * 1024,
                         "source": f"profiles/{tag}_{wl}_pmc.csv (FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE)"})
 if records:
