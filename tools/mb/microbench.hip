@@ -54,6 +54,39 @@ __global__ void k_fma64(double* out, int iters) {      // 8 independent f64 FMA 
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) out[0] = a0;
 }
 
+// HBM streams of the PS kernel's size: 400 MB in, 400 MB out
+template <int PER, bool NT>
+__global__ void __launch_bounds__(1024) k_copy(const int4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    const size_t base = ((size_t)blockIdx.x * PER) * blockDim.x + threadIdx.x;
+    int4 v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { const size_t i = base + (size_t)q * blockDim.x; v[q] = i < n4 ? in[i] : make_int4(0, 0, 0, 0); }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const size_t i = base + (size_t)q * blockDim.x;
+        if (i < n4) {
+            const float4 f = make_float4((float)v[q].x, (float)v[q].y, (float)v[q].z, (float)v[q].w);
+            if (NT) {
+                float* o = reinterpret_cast<float*>(out + i);
+                __builtin_nontemporal_store(f.x, o); __builtin_nontemporal_store(f.y, o + 1);
+                __builtin_nontemporal_store(f.z, o + 2); __builtin_nontemporal_store(f.w, o + 3);
+            } else out[i] = f;
+        }
+    }
+}
+__global__ void __launch_bounds__(1024) k_read(const int4* __restrict__ in, int* __restrict__ sink, size_t n4) {
+    const size_t base = ((size_t)blockIdx.x * 4) * blockDim.x + threadIdx.x;
+    int acc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const size_t i = base + (size_t)q * blockDim.x; if (i < n4) { const int4 v = in[i]; acc += v.x ^ v.y ^ v.z ^ v.w; } }
+    if (acc == 0x7fffffff) sink[0] = acc;
+}
+__global__ void __launch_bounds__(1024) k_write(float4* __restrict__ out, size_t n4) {
+    const size_t base = ((size_t)blockIdx.x * 4) * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const size_t i = base + (size_t)q * blockDim.x; if (i < n4) out[i] = make_float4(1.f, 2.f, 3.f, (float)i); }
+}
+
 template <typename F> float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -79,6 +112,19 @@ int main() {
         float ms = timeit([&] { k_fma64<<<2048, 1024>>>((double*)d, it64); });
         const double fmas = 2048.0 * 1024 * 8 * it64;
         printf("f64 FMA rate: %.2f T FMA lane-ops/s (= %.1f TFLOP/s), %.3f ms\n", fmas / (ms * 1e-3) / 1e12, 2 * fmas / (ms * 1e-3) / 1e12, ms);
+    }
+    {
+        const size_t bytes = 400u << 20, n4 = bytes / 16;
+        int4* din; float4* dout; hipMalloc(&din, bytes); hipMalloc(&dout, bytes); hipMemset(din, 1, bytes);
+        auto rep = [&](const char* name, float ms, double gb) { printf("%-34s %.4f ms  %.2f TB/s\n", name, ms, gb / ms); };
+        for (int r = 0; r < 2; ++r) {
+            rep("copy 400+400 MB, 4 vec/thread", timeit([&] { k_copy<4, false><<<(unsigned)((n4 + 4095) / 4096), 1024>>>(din, dout, n4); }), 0.8388608);
+            rep("copy, 4 vec/thread, nontemporal st", timeit([&] { k_copy<4, true><<<(unsigned)((n4 + 4095) / 4096), 1024>>>(din, dout, n4); }), 0.8388608);
+            rep("copy, 1 vec/thread", timeit([&] { k_copy<1, false><<<(unsigned)((n4 + 1023) / 1024), 1024>>>(din, dout, n4); }), 0.8388608);
+            rep("copy, 8 vec/thread", timeit([&] { k_copy<8, false><<<(unsigned)((n4 + 8191) / 8192), 1024>>>(din, dout, n4); }), 0.8388608);
+            rep("read 400 MB", timeit([&] { k_read<<<(unsigned)((n4 + 4095) / 4096), 1024>>>(din, (int*)d, n4); }), 0.4194304);
+            rep("write 400 MB", timeit([&] { k_write<<<(unsigned)((n4 + 4095) / 4096), 1024>>>(dout, n4); }), 0.4194304);
+        }
     }
     return 0;
 }
