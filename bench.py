@@ -623,6 +623,23 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
     if verify:
         ok, checked = wl.verify()
         v = {"ok": ok, "checked": checked}
+    if wl.key == "quant" and launches and hasattr(wl, "d_counts") and hasattr(wl, "d_ps"):
+        # what a device-to-device copy of the same byte volume (count table -> PS table) takes on THIS box, measured after
+        # the timed region and the verification (it overwrites the PS table): the bandwidth ceiling the PS kernel can be held against besides the spec figure
+        try:
+            nbytes = int(wl.alg_bytes // 2)
+            for _ in range(2):
+                ctx.copy2d_dev(wl.d_ps.ptr, nbytes, wl.d_counts.ptr, nbytes, nbytes, 1)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(5):
+                ctx.copy2d_dev(wl.d_ps.ptr, nbytes, wl.d_counts.ptr, nbytes, nbytes, 1)
+            copy_ms = ctx.timer_stop() / 5
+            roofline["copy_same_bytes_ms"] = copy_ms
+            roofline["frac_of_copy_same_bytes"] = copy_ms / avg_ms
+        except Exception as e:                       # the figure is a reference point, never a reason to fail the line
+            roofline["copy_same_bytes_ms"] = None
+            roofline["copy_error"] = str(e)[:120]
     return elapsed, roofline, v
 
 
