@@ -87,6 +87,30 @@ __global__ void __launch_bounds__(1024) k_write(float4* __restrict__ out, size_t
     for (int q = 0; q < 4; ++q) { const size_t i = base + (size_t)q * blockDim.x; if (i < n4) out[i] = make_float4(1.f, 2.f, 3.f, (float)i); }
 }
 
+// lane-xor exchanges by DPP (no LDS crossbar): 1, 2 = quad_perm; 4, 8 = two row shifts with bank masks
+__device__ __forceinline__ unsigned lane_xor_dpp(unsigned x, int lm) {
+    if (lm == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false);
+    if (lm == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false);
+    if (lm == 4) {
+        const int r = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xF, 0xA, false);
+    }
+    if (lm == 8) {
+        const int r = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x108, 0xF, 0x3, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(r, (int)x, 0x118, 0xF, 0xC, false);
+    }
+    return (unsigned)__shfl_xor((int)x, lm);
+}
+__global__ void k_dpp_check(unsigned* out) {
+    const unsigned x = threadIdx.x * 7u + 3u;
+    unsigned bad = 0;
+    bad |= lane_xor_dpp(x, 1) != (unsigned)__shfl_xor((int)x, 1) ? 1u : 0u;
+    bad |= lane_xor_dpp(x, 2) != (unsigned)__shfl_xor((int)x, 2) ? 2u : 0u;
+    bad |= lane_xor_dpp(x, 4) != (unsigned)__shfl_xor((int)x, 4) ? 4u : 0u;
+    bad |= lane_xor_dpp(x, 8) != (unsigned)__shfl_xor((int)x, 8) ? 8u : 0u;
+    out[threadIdx.x] = bad;
+}
+
 template <typename F> float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -95,6 +119,11 @@ template <typename F> float timeit(F f) {
 }
 int main() {
     void* d; hipMalloc(&d, 1 << 20);
+    {
+        unsigned h[64]; k_dpp_check<<<1, 64>>>((unsigned*)d); hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+        unsigned any = 0; for (int i = 0; i < 64; ++i) any |= h[i];
+        printf("DPP lane-xor self-check: mismatch mask %u (0 = all of xor 1, 2, 4, 8 agree with __shfl_xor)\n", any);
+    }
     const int it = 1 << 14;
     for (int rep = 0; rep < 2; ++rep) {
         for (int wgs : {256, 2048}) for (int th : {256, 1024}) {
