@@ -296,7 +296,19 @@ int sdice_prof_report(sdice_ctx* ctx, char* buf, int cap);
 int sdice_timer_start(sdice_ctx* ctx);
 int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms);
 
-/* tuning knob (integer parameters by name, e.g. "ps.tile_rows"); unknown name -> ERR_ARG */
+/* Tuning and test knobs (integer parameters by name); unknown name -> ERR_ARG.  Defaults are the measured optima.
+ *   ps.lds_bytes (81920)  ps.threads (1024)  ps.tile_rows (0 = from the LDS budget)  ps.halo_rows (-1 = 16 or the clustering's
+ *     reach)  ps.chunk_cols (0 = all columns up to 256, else 128)  ps.xcd_remap (1)  ps.quantize3 (0; 1 = store the '.3f'
+ *     round trip of PS)  ps.ablate (timing experiments of the ablation instantiations only)
+ *   cluster.generic / cluster.legacy (0; 1 = the radix-sort path)  cluster.sample_sort (1)  cluster.bucket_mean (2048)
+ *     cluster.spb (8 samples per bucket)  cluster.lds_cap (8192; small values force the in-HBM sort: tests)  cluster.ablate
+ *     (only in a library built with -DSDICE_CLUSTER_ABLATE=1)
+ *   ranksum.variant (0 auto, 1 lane, 2 block, 3 wave, 4 float lane pair, 5 counting)  ranksum.ablate (timing experiments)
+ *   fisher.table_max (1 << 20 log-factorials; small values force the lgamma path: tests)  fisher.refill (16 idle lanes before
+ *     the next pairs are fetched)  fisher.unroll (8 walk steps per trip: 1, 2, 4, 6 or 8)
+ *   bh.columns_path (0 by size, 1 radix, 2 sample sort)  bh.mean (160 values per bucket)  bh.spb (8 samples per bucket)
+ *     bh.reg_cap (1024; small values force the in-HBM bucket sort: tests)
+ *   sort.rounds (radix-sort scheduling experiment) */
 int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus
