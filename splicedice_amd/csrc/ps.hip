@@ -275,6 +275,10 @@ __device__ __forceinline__ void ps_tile_work(const PsArgs& a, const int bid, con
     const int slo = (int)max((int64_t)0, r0 - a.halo);
     const int shi = (int)min(a.n, r0 + nr + a.halo);
     const int wrows = shi - slo;
+    // A wave that is sending out its window loads goes ahead of the waves that are gathering: the memory pipe stays fed
+    // while the co-resident workgroup computes (measured in one process: 0.1845 -> 0.1757 ms at 1 M x 100, 2.02 -> 1.82 ms
+    // at 2 M x 500; priority levels 1..3 are equivalent, holding it until the first barrier is worse).
+    __builtin_amdgcn_s_setprio(3);
     if (tid < 3) red[tid] = 0u;                 // [0] max count, [1] max degree, [2] a staged neighbour is outside the window
     for (int i = tid; i < a.chunk_cols; i += T) tileL[(size_t)win_cap * a.chunk_cols + i] = 0;
     const int zero_off = win_cap * a.chunk_cols * 4;
@@ -323,6 +327,7 @@ __device__ __forceinline__ void ps_tile_work(const PsArgs& a, const int bid, con
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- CSR segment -> LDS: relative row pointers, neighbour LDS offsets, max degree
     const int64_t nk = a.row_ptr[r0 + nr] - kbase;
     const bool col_in_lds = nk <= (int64_t)a.col_cap;
