@@ -436,12 +436,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             constexpr int RB = 16;
             for (int r0 = 0; r0 < 32; r0 += RB) {
                 float x0[RB], x1[RB];
+                __builtin_amdgcn_s_setprio(3);          // (loads first: ~1 % -- see ps.hip)
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
                     const int rc = min(r0 + q, rows_avail - 1);
                     x0[q] = act0 ? gbase[rc * s + sel0] : 0.f;
                     x1[q] = act1 ? gbase[rc * s + sel1] : 0.f;
                 }
+                __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
                     const int r = r0 + q;
@@ -1024,11 +1026,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
       for (int ri = 0; ri < rows_here; ++ri) {
         const float* prow = ps + (row0 + ri) * s;
         float x[E], y[E];
+        __builtin_amdgcn_s_setprio(3);                  // (loads first: ~1 % -- see ps.hip)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             x[e] = idx1[e] >= 0 ? prow[idx1[e]] : __builtin_nanf("");
             y[e] = idx2[e] >= 0 ? prow[idx2[e]] : __builtin_nanf("");
         }
+        __builtin_amdgcn_s_setprio(0);
         // bin of every value and the check that the value IS its bin's float; kk[e] packs (bin + 1) of the
         // group-1 value in the low half and of the group-2 value in the high half, 0 = NaN
         unsigned kk[E];
