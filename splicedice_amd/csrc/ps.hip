@@ -50,6 +50,7 @@ struct PsArgs {
     int n_tiles;
     int tiles_per_xcd;  // 0 = no remap
     int n_chunks;       // column chunks per row tile
+    int prio;           // raise the wave priority while the window loads go out (param ps.prio, default 1)
 };
 
 template <int VEC> struct Vt;
@@ -278,7 +279,7 @@ __device__ __forceinline__ void ps_tile_work(const PsArgs& a, const int bid, con
     // A wave that is sending out its window loads goes ahead of the waves that are gathering: the memory pipe stays fed
     // while the co-resident workgroup computes (measured in one process: 0.1845 -> 0.1757 ms at 1 M x 100, 2.02 -> 1.82 ms
     // at 2 M x 500; priority levels 1..3 are equivalent, holding it until the first barrier is worse).
-    __builtin_amdgcn_s_setprio(3);
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     if (tid < 3) red[tid] = 0u;                 // [0] max count, [1] max degree, [2] a staged neighbour is outside the window
     for (int i = tid; i < a.chunk_cols; i += T) tileL[(size_t)win_cap * a.chunk_cols + i] = 0;
     const int zero_off = win_cap * a.chunk_cols * 4;
@@ -327,7 +328,7 @@ __device__ __forceinline__ void ps_tile_work(const PsArgs& a, const int bid, con
             }
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
     // ---- CSR segment -> LDS: relative row pointers, neighbour LDS offsets, max degree
     const int64_t nk = a.row_ptr[r0 + nr] - kbase;
     const bool col_in_lds = nk <= (int64_t)a.col_cap;
@@ -521,6 +522,7 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     a.n_tiles = (int)sd_ceil_div(n, R);
     const int n_chunks = (int)sd_ceil_div(s, cw);
     a.n_chunks = n_chunks;
+    a.prio = ctx->param("ps.prio", 1) != 0;
     int gx = a.n_tiles;
     a.tiles_per_xcd = 0;
     const int abl = (int)ctx->param("ps.ablate", 0);
