@@ -645,10 +645,10 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
 
 # what "also" reports at N=1: (key, workload class, n, s, rows of the repeated host block, steps, CPU sample)
 ALSO = [
-    ("quant_2m500", "quant", 2_000_000, 500, 200_000, 5, 100_000),         # the north-star size
-    ("compare_c3", "compare", 1_000_000, 100, 200_000, 10, 30_000),        # BASELINE config 3
-    ("pairwise_c4_shard", "pairwise", 25_000, 200, 0, 2, 10),              # config 4, one GPU's shard of 8
-    ("e2e_c5_shard", "e2e", 625_000, 1000, 125_000, 3, 12_000),            # config 5, one GPU's shard of 8
+    ("quant_2m500", "quant", 2_000_000, 500, 200_000, 20, 100_000),         # the north-star size
+    ("compare_c3", "compare", 1_000_000, 100, 200_000, 30, 30_000),        # BASELINE config 3
+    ("pairwise_c4_shard", "pairwise", 25_000, 200, 0, 4, 10),              # config 4, one GPU's shard of 8
+    ("e2e_c5_shard", "e2e", 625_000, 1000, 125_000, 10, 12_000),            # config 5, one GPU's shard of 8
 ]
 
 
@@ -756,8 +756,8 @@ def main():
             try:
                 w = WORKLOADS[kind](ctx, 0, n, s, block)
                 w.key = kind
-                el, rl, vf = measure(ctx, w, dist, steps, 2, 1, not args.no_verify)
-                rec = {"metric": w.metric, "value": w.units * steps / el, "unit": w.unit, "steps": steps, "warmup": 2,
+                el, rl, vf = measure(ctx, w, dist, steps, 5, 1, not args.no_verify)      # (enough steps for the clocks to settle)
+                rec = {"metric": w.metric, "value": w.units * steps / el, "unit": w.unit, "steps": steps, "warmup": 5,
                        "ms_per_step": el / steps * 1e3, "dtype": w.dtype, "config": w.describe(), "roofline": rl,
                        "verify": vf, "gen_seconds": round(w.gen_s, 1)}
                 if not args.no_cpu_baseline:
