@@ -63,8 +63,8 @@ F64_WAVE_INSTS_PER_S = 5.25e11   # measured f64 FMA issue rate (tools/mb/microbe
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # (a 0.37 ms step: 20 steps end before the clocks have settled, +3 %)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["quant", "compare", "pairwise", "e2e"], default="quant")
     # (long names only: under torch.distributed.run a short "--n" is swallowed by the launcher's parser)
     ap.add_argument("--junctions", dest="n", type=int, default=0, help="junctions per GPU (default: the BASELINE config)")
