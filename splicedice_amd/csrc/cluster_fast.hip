@@ -70,7 +70,6 @@ struct FastArgs {
     int lds_cap;           // elements the sort kernel may hold in LDS
     unsigned long long* sb;   // status block
     uint32_t* rank;        // [S]
-    uint64_t* spl;         // [B] splitters (chrom << 32 | left)
     uint32_t* cursor;      // [B]
     uint4* slots;          // [B * slot_cap]
     uint32_t* rowC; uint32_t* rowL; uint32_t* rowR2;   // row-order arrays [n]
@@ -122,14 +121,6 @@ __global__ void __launch_bounds__(256) sample_rank_kernel(FastArgs a) {
     if (i < a.S && cnt) atomicAdd(&a.rank[i], cnt);
 }
 
-// every SPB-th sample key in rank order is a splitter
-__global__ void __launch_bounds__(256) splitter_kernel(FastArgs a) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= a.S) return;
-    const uint32_t rk = a.rank[q];
-    if (rk != 0 && rk % a.spb == 0) a.spl[rk / a.spb - 1] = sample_key(a, q);      // slots 0 .. B-2
-}
-
 // ------------------------------------------------------------------ 2. classify + scatter into slots
 constexpr int SC_KPT = 4;
 template <int T>
@@ -143,7 +134,14 @@ __global__ void __launch_bounds__(T) bucket_scatter_kernel(FastArgs a) {
     __shared__ uint32_t s_bad, s_over;
     const int t = threadIdx.x;
     if (t == 0) { s_bad = 0; s_over = 0; }
-    for (int b = t; b < B; b += T) { spl[b] = b < B - 1 ? a.spl[b] : ~0ull; cnt[b] = 0; }
+    // every spb-th sample key in rank order is a splitter: each workgroup picks them out of the rank table itself
+    // (S rank reads from L2, B - 1 sample keys) -- a separate 5 us launch did nothing else
+    for (int b = t; b < B; b += T) { spl[b] = ~0ull; cnt[b] = 0; }
+    __syncthreads();
+    for (int q = t; q < a.S; q += T) {
+        const uint32_t rk = a.rank[q];
+        if (rk != 0 && rk % (uint32_t)a.spb == 0) spl[rk / (uint32_t)a.spb - 1] = sample_key(a, q);      // slots 0 .. B-2
+    }
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * T * SC_KPT;
     uint32_t kc[SC_KPT], kl[SC_KPT], kr[SC_KPT], bk[SC_KPT], lr[SC_KPT];
@@ -990,8 +988,7 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
     a.rowC = (uint32_t*)A.alloc((size_t)n * 4);
     a.rowL = (uint32_t*)A.alloc((size_t)n * 4);
     a.rowR2 = (uint32_t*)A.alloc((size_t)n * 4);
-    a.spl = (uint64_t*)A.alloc((size_t)a.B * 8);
-    if (!z || !a.slots || !a.rowC || !a.rowL || !a.rowR2 || !a.spl) return SDICE_ERR_NOMEM;
+    if (!z || !a.slots || !a.rowC || !a.rowL || !a.rowR2) return SDICE_ERR_NOMEM;
     pl.zero_base = z;
     pl.k4_zero_bytes = zk4;
     pl.zero_bytes = zk4 + zrest;
@@ -1114,7 +1111,6 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     if (a.S > 0) {
         const unsigned g = grid_for(a.S, 256);
         SD_LAUNCH(ctx, "sample_rank_kernel", sample_rank_kernel, dim3(g, g), dim3(256), 0, a);
-        SD_LAUNCH(ctx, "splitter_kernel", splitter_kernel, dim3(g), dim3(256), 0, a);
     }
     {
         const size_t lds = (size_t)a.B * 16;
