@@ -350,7 +350,7 @@ def test_ranksum_kat(ctx, golden_dir):
 
 
 @pytest.mark.parametrize("n1,n2,s,variant", [(50, 50, 100, 0), (50, 50, 100, 2), (3, 3, 6, 0), (3, 3, 6, 2),
-                                              (64, 64, 130, 0), (7, 33, 64, 0), (9, 17, 40, 0), (65, 10, 80, 0),
+                                              (64, 64, 130, 0), (63, 64, 130, 0), (64, 63, 130, 0), (7, 33, 64, 0), (9, 17, 40, 0), (65, 10, 80, 0),
                                               (500, 500, 1000, 0), (500, 500, 1000, 2), (200, 130, 400, 0),
                                               (200, 130, 400, 2), (1500, 3, 1600, 0), (1024, 1000, 2100, 0),
                                               (50, 50, 100, 3), (3, 3, 6, 3), (128, 65, 200, 3), (300, 7, 400, 3),
