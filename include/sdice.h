@@ -299,7 +299,8 @@ int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms);
 /* Tuning and test knobs (integer parameters by name); unknown name -> ERR_ARG.  Defaults are the measured optima.
  *   ps.lds_bytes (81920)  ps.threads (1024)  ps.tile_rows (0 = from the LDS budget)  ps.halo_rows (-1 = 16 or the clustering's
  *     reach)  ps.chunk_cols (0 = all columns up to 256, else 128)  ps.xcd_remap (1)  ps.quantize3 (0; 1 = store the '.3f'
- *     round trip of PS)  ps.prio (1 = window loads at raised wave priority)  ps.ablate (timing experiments of the ablation instantiations only)
+ *     round trip of PS)  ps.prio (1 = window loads at raised wave priority)  ps.nt_loads (1 = non-temporal window
+ *     loads when the table is not cut into column chunks)  ps.ablate (timing experiments of the ablation instantiations only)
  *   cluster.generic / cluster.legacy (0; 1 = the radix-sort path)  cluster.sample_sort (1)  cluster.bucket_mean (2048)
  *     cluster.spb (8 samples per bucket)  cluster.lds_cap (8192; small values force the in-HBM sort: tests)  cluster.ablate
  *     (only in a library built with -DSDICE_CLUSTER_ABLATE=1)

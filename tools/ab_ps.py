@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-process interleaved A/B of PS launch configurations: ab_ps.py n s lds:threads[:prio] lds:threads[:prio] ..."""
+"""Same-process interleaved A/B of PS launch configurations: ab_ps.py n s lds:threads[:bits] ... (bits: 1 = load-phase priority, 2 = non-temporal window loads; default 3)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,7 +22,7 @@ for _ in range(10):
 ctx.sync()
 for rep in range(4):
     for c in cfgs:
-        ctx.set_param("ps.lds_bytes", c[0]); ctx.set_param("ps.threads", c[1]); ctx.set_param("ps.halo_rows", -1); ctx.set_param("ps.prio", c[2] if len(c) > 2 else 1)
+        ctx.set_param("ps.lds_bytes", c[0]); ctx.set_param("ps.threads", c[1]); ctx.set_param("ps.halo_rows", -1); ctx.set_param("ps.prio", (c[2] & 1) if len(c) > 2 else 1); ctx.set_param("ps.nt_loads", ((c[2] >> 1) & 1) if len(c) > 2 else 1)
         for _ in range(3):
             ctx.ps_dev(d_counts, d_rp, d_col, None, d_ps)
         ctx.sync()
@@ -30,4 +30,4 @@ for rep in range(4):
         for _ in range(30):
             ctx.ps_dev(d_counts, d_rp, d_col, None, d_ps)
         ms = ctx.timer_stop() / 30
-        print(f"rep {rep} lds={c[0]} threads={c[1]} prio={c[2] if len(c) > 2 else 1}: {ms:.4f} ms  {n * s * 8 / ms / 1e6:.0f} GB/s", flush=True)
+        print(f"rep {rep} lds={c[0]} threads={c[1]} bits={c[2] if len(c) > 2 else 3}: {ms:.4f} ms  {n * s * 8 / ms / 1e6:.0f} GB/s", flush=True)
