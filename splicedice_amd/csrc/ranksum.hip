@@ -440,8 +440,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
                     const int rc = min(r0 + q, rows_avail - 1);
-                    x0[q] = act0 ? gbase[rc * s + sel0] : 0.f;
-                    x1[q] = act1 ? gbase[rc * s + sel1] : 0.f;
+                    x0[q] = act0 ? __builtin_nontemporal_load(gbase + rc * s + sel0) : 0.f;      // (read once: -2 %)
+                    x1[q] = act1 ? __builtin_nontemporal_load(gbase + rc * s + sel1) : 0.f;
                 }
                 __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -1029,8 +1029,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
         __builtin_amdgcn_s_setprio(3);                  // (loads first: ~1 % -- see ps.hip)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            x[e] = idx1[e] >= 0 ? prow[idx1[e]] : __builtin_nanf("");
-            y[e] = idx2[e] >= 0 ? prow[idx2[e]] : __builtin_nanf("");
+            x[e] = idx1[e] >= 0 ? __builtin_nontemporal_load(prow + idx1[e]) : __builtin_nanf("");
+            y[e] = idx2[e] >= 0 ? __builtin_nontemporal_load(prow + idx2[e]) : __builtin_nanf("");
         }
         __builtin_amdgcn_s_setprio(0);
         // bin of every value and the check that the value IS its bin's float; kk[e] packs (bin + 1) of the
