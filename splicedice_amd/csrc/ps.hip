@@ -226,7 +226,7 @@ __device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB,
         if (col_in_lds) {
             off = colL[k];
         } else {
-            const int j = a.col[kbase + k];
+            const int j = a.nt ? __builtin_nontemporal_load(a.col + kbase + k) : a.col[kbase + k];
             const unsigned rel = (unsigned)(j - slo);
             off = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
         }
