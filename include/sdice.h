@@ -302,7 +302,7 @@ int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms);
  *     round trip of PS)  ps.prio (1 = window loads at raised wave priority)  ps.nt_loads (1 = non-temporal window
  *     loads when the table is not cut into column chunks)  ps.ablate (timing experiments of the ablation instantiations only)
  *   cluster.generic / cluster.legacy (0; 1 = the radix-sort path)  cluster.sample_sort (1)  cluster.bucket_mean (2048)
- *     cluster.spb (8 samples per bucket)  cluster.lds_cap (8192; small values force the in-HBM sort: tests)  cluster.ablate
+ *     cluster.spb (0 = 12 samples per bucket up to 2 M junctions, 8 beyond)  cluster.lds_cap (8192; small values force the in-HBM sort: tests)  cluster.ablate
  *     (only in a library built with -DSDICE_CLUSTER_ABLATE=1)
  *   ranksum.variant (0 auto, 1 lane, 2 block, 3 wave, 4 float lane pair, 5 counting)  ranksum.ablate (timing experiments)
  *   fisher.table_max (1 << 20 log-factorials; small values force the lgamma path: tests)  fisher.refill (16 idle lanes before

@@ -7,6 +7,8 @@ from splicedice_amd import synth
 from splicedice_amd.engine import Context
 n, s = int(sys.argv[1]), int(sys.argv[2])
 cfgs = sys.argv[3:] or [""]
+DEFAULTS = {"cluster.spb": 0, "cluster.bucket_mean": 2048, "cluster.sample_sort": 1, "ps.prio": 1, "ps.nt_loads": 1, "ps.halo_rows": -1,
+            "ps.tile_rows": 0, "ps.lds_bytes": 81920, "ps.threads": 1024}
 ctx = Context(0)
 junc = synth.make_junctions(n, 2)
 d = [ctx.to_device(x) for x in junc]
@@ -30,5 +32,5 @@ for rep in range(3):
         for _ in range(200): step()
         ms = ctx.timer_stop() / 200
         ctx.sync()
-        for k, v in kv: ctx.set_param(k, 0)
+        for k, v in kv: ctx.set_param(k, DEFAULTS.get(k, 0))
         print(f"rep {rep} [{c}] {ms:.4f} ms per step  {n * s / ms / 1e6:.1f} G entries/s", flush=True)
