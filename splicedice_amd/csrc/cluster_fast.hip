@@ -667,7 +667,7 @@ struct NbCfg {
     static constexpr int HB = 256;             // rows staged before the tile
     static constexpr int HF = 128;             // rows staged after it
     static constexpr int W = T + HB + HF;
-    static constexpr int STAGE = 12 * T;       // list entries staged in LDS per tile
+    static constexpr int STAGE = 11 * T;       // list entries staged in LDS per tile (11, not 12: 40 120 B per workgroup -> FOUR per CU)
     static constexpr int KMAX = 16;            // entries a row keeps from its (single) walk, as 16-bit row distances
     static constexpr int WIN_WORDS = 6 * W;    // cL, running maximum (64 bit each), right, window index + position (16 bit each)
     static constexpr int UNION_WORDS = WIN_WORDS > STAGE ? WIN_WORDS : STAGE;
@@ -697,7 +697,7 @@ __device__ __forceinline__ void walk_fwd_global(const FastArgs& a, int q, int n,
 }
 
 template <int T>
-__global__ void __launch_bounds__(T, (3 * T) / 256) neighbours_kernel(FastArgs a) {      // three workgroups per CU
+__global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // four workgroups per CU (three: +3 % on the quant step)
     typedef NbCfg<T> Cfg;
     constexpr int W = Cfg::W, KMAX = Cfg::KMAX;
     constexpr int EPT = (W + T - 1) / T;       // window rows per thread while the window is built
