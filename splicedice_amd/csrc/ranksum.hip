@@ -998,7 +998,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
                                                             RsOut o) {
     extern __shared__ __align__(16) float smemc[];
     constexpr int N = 64 * E;
-    constexpr int WSTRIDE = 2 * N + 40 + RS_BINS + 8;
+    // for E >= 8 the histogram lives in the SA | SB area (1024 words): the compacted values are dead once the two pairwise sums
+    // are taken, and 4 KB less per wave lets a fifth wave per SIMD in (the kernel is latency bound)
+    constexpr bool H_ALIAS = 2 * N >= RS_BINS;
+    constexpr int WSTRIDE = 2 * N + 40 + (H_ALIAS ? 0 : RS_BINS) + 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     float* T = smemc;                                          // T[k] = float32(k / 1000.0), shared by the block
@@ -1006,7 +1009,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
     float* SB = SA + N;
     float* leaf_sum = SB + N;
     int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);
-    unsigned* H = reinterpret_cast<unsigned*>(SB + N + 40);    // [RS_BINS] a_v | b_v << 16
+    unsigned* H = H_ALIAS ? reinterpret_cast<unsigned*>(SA) : reinterpret_cast<unsigned*>(SB + N + 40);    // [RS_BINS] a_v | b_v << 16
     for (int k = threadIdx.x; k < 1008; k += blockDim.x) T[k] = (float)((double)k / 1000.0);
     __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1075,9 +1078,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
             if (v2) SB[nv2 + __popcll(m2 & lt_mask)] = y[e];
             nv2 += __popcll(m2);
         }
-        // clear the histogram: 16 words per lane
+        // clear the histogram: 16 words per lane (when it shares the SA | SB area: after the sums)
+        if (!H_ALIAS) {
 #pragma unroll
-        for (int q = 0; q < RS_BINS / 64 / 4; ++q) reinterpret_cast<uint4*>(H)[lane * (RS_BINS / 64 / 4) + q] = make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < RS_BINS / 64 / 4; ++q) reinterpret_cast<uint4*>(H)[lane * (RS_BINS / 64 / 4) + q] = make_uint4(0, 0, 0, 0);
+        }
         SD_WAVE_SYNC();
         if (nv1 < 3 || nv2 < 3) {          // wave-uniform
             if (lane == ri) { s_nv1 = nv1; s_nv2 = nv2; }
@@ -1085,6 +1090,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
         }
         const float sum1 = wave_pairwise_sum(SA, nv1, lane, leaf_off, leaf_sum);
         const float sum2 = wave_pairwise_sum(SB, nv2, lane, leaf_off, leaf_sum);
+        if (H_ALIAS) {
+            SD_WAVE_SYNC();                 // every lane has read its values
+#pragma unroll
+            for (int q = 0; q < RS_BINS / 64 / 4; ++q) reinterpret_cast<uint4*>(H)[lane * (RS_BINS / 64 / 4) + q] = make_uint4(0, 0, 0, 0);
+            SD_WAVE_SYNC();
+        }
         // histogram: ballots for the two heavy bins, LDS atomics for the rest
         unsigned c_lo = 0, c_hi = 0;         // packed (group 1 | group 2 << 16) counts of bins 0 and 1000
 #pragma unroll
@@ -1212,7 +1223,7 @@ int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     if (blocks > cap) blocks = cap;
     if (counting) {
         // histogram path for rows of 3-decimal PS values; the sorting kernel then takes the rows it marked
-        const size_t lds_c = (size_t)(1008 + waves * (2 * 64 * E + 40 + RS_BINS + 8)) * 4;
+        const size_t lds_c = (size_t)(1008 + waves * (2 * 64 * E + 40 + (2 * 64 * E >= RS_BINS ? 0 : RS_BINS) + 8)) * 4;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_count_kernel<E>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         SD_LAUNCH(ctx, "ranksum_count_kernel", (ranksum_count_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds_c,
