@@ -108,6 +108,19 @@ int sdice_ps(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* counts,
 int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* d_counts,
                  const int64_t* d_row_ptr, const int32_t* d_col, int64_t* d_excl, float* d_ps);
 
+/* ---- PS of a float64 count table: counts_to_ps.writePsValues (counts_to_ps.py:58-70) as written --
+ *      the table is parsed with dtype=float (:50), so fractional / normalised counts are legal there.
+ *  counts[n_rows,s] float64 row-major; rows 0..n_out-1 get a result, rows n_out..n_rows-1 are
+ *  sources only (overlaps that are named in a cluster list but are not cluster keys themselves);
+ *  row_ptr[n_out+1], col[nnz] with 0 <= col < n_rows.
+ *  ps[n_out,s] float64 = counts[r] / (counts[r] + counts[col[k0]] + counts[col[k0+1]] + ...), the sum
+ *  taken left to right in list order, one IEEE addition at a time; 0/0 -> NaN, x/0 -> inf.
+ */
+int sdice_ps_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* counts,
+                 const int64_t* row_ptr, const int32_t* col, double* ps);
+int sdice_ps_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
+                     const int64_t* d_row_ptr, const int32_t* d_col, double* d_ps);
+
 /* --lowCoverageNan (SPLICEDICE.py:307-309): ps[low_idx[i]] = NaN, flat indices r*s+c */
 int sdice_mark_low(sdice_ctx* ctx, int64_t n_elems, float* ps, const int64_t* low_idx,
                    int64_t n_low);

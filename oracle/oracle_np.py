@@ -124,6 +124,24 @@ def calculate_psi_vectorised(counts, row_ptr, col):
     return psi, excl
 
 
+def write_ps_values_f64(counts, row_ptr, col, n_out=None):
+    """counts_to_ps.py:58-70 (writePsValues) on a float64 table: `exclusion = counts[j].copy()`, then
+    `exclusion += counts[overlap]` per list entry in list order, `ps = counts[j] / exclusion`.
+    counts [n_rows,s] float64 (fractional values allowed: the reference parses with dtype=float, :50);
+    rows n_out.. are sources only.  Returns ps float64 [n_out,s]."""
+    counts = np.asarray(counts, dtype=np.float64)
+    n_rows, s = counts.shape
+    n_out = n_rows if n_out is None else n_out
+    ps = np.empty((n_out, s), dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for r in range(n_out):
+            exclusion = counts[r].copy()
+            for k in range(row_ptr[r], row_ptr[r + 1]):
+                exclusion += counts[col[k]]
+            ps[r] = counts[r] / exclusion
+    return ps
+
+
 def quantize3(ps):
     """The `_allPS.tsv` text round trip: f'{x:.3f}' (SPLICEDICE.py:353) re-read as
     float32 (compareSampleSets.py:202)."""

@@ -6,9 +6,10 @@ and writes `<prefix>_allClusters.tsv` (sorted by raw string, :76); both write
 `<prefix>_allPS.tsv` in tuple order (:61).
 
 On the GPU: determine_clusters (:16-41) -> sdice_cluster; the per-junction sum of the
-overlapping count rows (:63-67) -> sdice_ps (integer exclusion sums).  The quotient is taken
-in float64 on the host, because this sub-command prints the float64 quotient itself
-(`counts/exclusion`, :68-69) rather than a float32 as quant does.
+overlapping count rows and the quotient (:63-68) -> sdice_ps_f64: float64 throughout, sums in
+list order, as the reference's `dtype=float` rows are -- fractional / normalised count tables
+are legal input here, and this sub-command prints the float64 quotient itself rather than a
+float32 as quant does.
 """
 import numpy as np
 
@@ -43,12 +44,12 @@ def determine_clusters(counts_file, ctx):
 
 
 def get_counts(count_file):
-    """header line + name -> row index, int32 matrix (counts_to_ps.py:43-51)."""
+    """header line + name -> row index, float64 matrix (counts_to_ps.py:43-51: dtype=float)."""
     header, names, data = textio.read_table_numeric(count_file, np.float64)
     index = {}
     for i, name in enumerate(names):
         index[name] = i                           # a repeated name keeps its last row, as a dict would
-    return header, index, textio.counts_to_int32(data, count_file)
+    return header, index, np.ascontiguousarray(data, dtype=np.float64)
 
 
 def write_ps_values(clusters, header, index, counts, output_prefix, ctx):
@@ -73,13 +74,8 @@ def write_ps_values(clusters, header, index, counts, output_prefix, ctx):
             col.append(c)
         row_ptr[r + 1] = len(col)
     all_rows = np.concatenate([rows, np.asarray(extra, dtype=np.int64)]) if extra else rows
-    table = counts[all_rows] if len(all_rows) else np.zeros((0, counts.shape[1] if counts.ndim == 2 else 0), np.int32)
-    if extra:
-        row_ptr = np.concatenate([row_ptr, np.full(len(extra), row_ptr[-1], dtype=np.int64)])
-    excl = ctx.ps(table, row_ptr, np.asarray(col, dtype=np.int32), want_excl=True, want_ps=False)
-    own = table[:len(j_list)].astype(np.float64)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        ps = own / (own + excl[:len(j_list)].astype(np.float64))
+    table = counts[all_rows] if len(all_rows) else np.zeros((0, counts.shape[1] if counts.ndim == 2 else 0), np.float64)
+    ps = ctx.ps_f64(table, row_ptr, np.asarray(col, dtype=np.int32), n_out=len(j_list))
     textio.write_table(f"{output_prefix}_allPS.tsv", header, j_list, ps, ".3f")      # f"{x:0.3f}" on float64
 
 

@@ -167,6 +167,20 @@ class Context:
             return ps, excl
         return ps if want_ps else excl
 
+    def ps_f64(self, counts, row_ptr, col, n_out=None):
+        """-> ps float64[n_out,s] of a float64 count table, sums in list order (counts_to_ps.py:58-70).
+        Rows n_out.. of `counts` are sources only."""
+        counts = _c(counts, np.float64)
+        n_rows, s = counts.shape
+        n_out = n_rows if n_out is None else int(n_out)
+        row_ptr, col = _c(row_ptr, np.int64), _c(col, np.int32)
+        if row_ptr.size != n_out + 1:
+            raise ValueError("ps_f64: row_ptr must hold n_out + 1 entries")
+        ps = np.empty((n_out, s), dtype=np.float64)
+        check(self.lib.sdice_ps_f64(self.h, n_out, n_rows, s, _ptr(counts), _ptr(row_ptr), _ptr(col), _ptr(ps)),
+              "sdice_ps_f64")
+        return ps
+
     def mark_low(self, ps, low_flat_idx):
         ps = _c(ps, np.float32)
         idx = _c(low_flat_idx, np.int64)

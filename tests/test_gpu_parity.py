@@ -302,6 +302,51 @@ def test_ps_empty(ctx):
     assert ps.shape == (0, 5)
 
 
+@pytest.mark.parametrize("n,s,seed", [(900, 5, 1), (400, 100, 2), (300, 333, 3), (1200, 1, 4), (64, 64, 5)])
+def test_ps_f64_fractional_counts_vs_oracle(ctx, n, s, seed):
+    """counts_to_ps.py:58-70 on a float64 table: the sums round, so the ORDER of the additions shows in the last
+    bit -- bit-exact against the restated loop, on values spanning 16 decades, with negative zero, NaN and inf
+    cells, lists of 0..40 entries (the kernel adds them four at a time), source-only rows past n_out."""
+    rng = np.random.default_rng(seed)
+    n_out = n - n // 7
+    deg = rng.integers(0, 9, size=n_out)
+    deg[rng.integers(0, n_out, size=5)] = rng.integers(20, 41, size=5)
+    row_ptr = np.r_[0, np.cumsum(deg)].astype(np.int64)
+    col = rng.integers(0, n, size=int(row_ptr[-1])).astype(np.int32)
+    counts = rng.gamma(0.7, 30.0, size=(n, s)) * 10.0 ** rng.integers(-8, 9, size=(n, 1))
+    counts[rng.random((n, s)) < 0.2] = 0.0
+    flat = counts.reshape(-1)
+    flat[rng.integers(0, flat.size, size=6)] = [np.nan, np.inf, -0.0, -3.25, 1e-310, 1.7e308]
+    want = O.write_ps_values_f64(counts, row_ptr, col, n_out)
+    got = ctx.ps_f64(counts, row_ptr, col, n_out=n_out)
+    assert got.shape == (n_out, s)
+    assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist() or \
+        (np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]))
+
+
+def test_ps_f64_integer_table_equals_integer_kernel(ctx):
+    """On an integer-valued table the float64 sums are exact: same numbers as ps_tile_kernel's int64 sums."""
+    n, s = 3000, 37
+    cr, left, right, strand = synth.make_junctions(n, 9, n_chrom=3)
+    _, row_ptr, col = O.cluster_csr(cr, left, right, strand)
+    counts = synth.make_counts(n, s, 10)
+    excl = ctx.ps(counts, row_ptr, col, want_excl=True, want_ps=False)
+    own = counts.astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = own / (own + excl.astype(np.float64))
+    got = ctx.ps_f64(own, row_ptr, col)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_ps_f64_empty_and_bad_csr(ctx):
+    assert ctx.ps_f64(np.zeros((0, 4)), np.zeros(1, np.int64), np.zeros(0, np.int32)).shape == (0, 4)
+    assert ctx.ps_f64(np.ones((3, 0)), np.zeros(4, np.int64), np.zeros(0, np.int32)).shape == (3, 0)
+    with pytest.raises(Exception, match="out of range"):
+        ctx.ps_f64(np.ones((3, 2)), np.array([0, 1, 1, 1], np.int64), np.array([3], np.int32))
+    with pytest.raises(Exception, match="non-decreasing"):
+        ctx.ps_f64(np.ones((3, 2)), np.array([0, 2, 1, 2], np.int64), np.array([0, 1], np.int32))
+
+
 def test_mark_low_and_quantize(ctx):
     rng = np.random.default_rng(3)
     x = rng.random((50, 9)).astype(np.float32)

@@ -229,3 +229,36 @@ def test_find_outliers_restatement_vs_reference_output(golden_dir):
             lines = O.find_outlier_lines(z["rows"], z["cols"], z["data"], samples, grp, cut)
             want = open(os.path.join(d, f"expected_{tag}_{name}.txt")).read()
             assert "".join(line + "\n" for line in lines) == want, (tag, name)
+
+
+def test_write_ps_values_f64_vs_reference_output(golden_dir):
+    """The float64 PS restatement (counts_to_ps.py:58-70) pinned by the reference's own output on a fractional count
+    table (tests/golden/make_golden_fractional.py): same '0.3f' text for every cell."""
+    d = os.path.join(golden_dir, "counts_to_ps_fractional")
+    lines = open(os.path.join(d, "in_inclusionCounts.tsv")).read().splitlines()
+    names = [ln.split("\t", 1)[0] for ln in lines[1:]]
+    counts = np.array([ln.split("\t")[1:] for ln in lines[1:]], dtype=float)
+    index = {nm: i for i, nm in enumerate(names)}
+    clusters = {}
+    for ln in open(os.path.join(golden_dir, "quant_c1", "expected_default", "out_allClusters.tsv")):
+        j, ov = ln.rstrip("\n").split("\t")
+        clusters[j] = [o for o in ov.split(",") if o]
+
+    def key(nm):
+        c, co, st = nm.split(":")
+        a, b = co.split("-")
+        return (c, int(a), int(b), st)
+    order = sorted(clusters, key=key)
+    row_ptr = np.zeros(len(order) + 1, dtype=np.int64)
+    col = []
+    for r, nm in enumerate(order):
+        col.extend(index[o] for o in clusters[nm])
+        row_ptr[r + 1] = len(col)
+    table = counts[[index[nm] for nm in order]]
+    remap = {index[nm]: r for r, nm in enumerate(order)}
+    col = np.array([remap[c] for c in col], dtype=np.int32)
+    ps = O.write_ps_values_f64(table, row_ptr, col)
+    want = open(os.path.join(d, "expected_c", "out_allPS.tsv")).read().splitlines()
+    assert len(want) == len(order) + 1
+    for r, nm in enumerate(order):
+        assert want[r + 1] == nm + "\t" + "\t".join(f"{x:0.3f}" for x in ps[r])
