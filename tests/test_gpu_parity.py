@@ -729,6 +729,24 @@ def test_fisher_fuzz_tables(ctx):
     np.testing.assert_allclose(got[big], want[big], rtol=1e-7, atol=0)
 
 
+@pytest.mark.parametrize("table,want,scipy_says", [
+    ((41976, 5113, 372553, 78120), 6.575064524545e-310, 3.1204020472848e-310),
+    ((58002, 90233, 44143, 91836), 3.450966061159082e-300, 1.7711130111622034e-300)])
+def test_fisher_p_near_underflow_is_the_exact_sum(ctx, table, want, scipy_says):
+    """p-values of 1e-300 and below: scipy's answer is erratic there -- Boost's hypergeometric pmf returns spurious
+    zeros near the underflow limit (first table: pmf(36198) = 1.26e-310, pmf(36203) = 0, pmf(36205) = 3.0e-309; second
+    table: pmf(48545) = 1.0e-300, pmf(48546) = 0, pmf(48547) = 1.8e-300), fisher_exact's boundary search is misled and
+    the far tail drops out of the sum (scipy 1.15.3 returns `scipy_says`, the near tail alone) -- while the kernel's
+    ratio walk never leaves the normal range until the final product.  The kernel returns the EXACT two-sided sum:
+    `want` comes from rational arithmetic (tools/exact_fisher.py, ~5 min per table; both found by tools/fuzz_gpu.py)."""
+    a, b, c, d = table
+    got = ctx.fisher_tables(np.array([table], np.int64))[0]
+    assert abs(got - want) <= 1e-7 * want                    # (pmf(a) = exp of nine log-factorials of ~6e6: ~1e-9)
+    assert abs(got - scipy_says) > 0.4 * want
+    pair = ctx.fisher_pairs(np.array([[a, b]], np.int32), np.array([[c, d]], np.int64))[0, 0]      # the pair kernel
+    assert abs(pair - want) <= 1e-7 * want
+
+
 def test_cluster_fuzz(ctx):
     """random junction sets: tiny, one chromosome, identical coordinates on both strands, heavy overlap"""
     rng = np.random.default_rng(31337)

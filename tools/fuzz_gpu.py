@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Extended differential campaign: the HIP path against the oracle on random ADVERSARIAL inputs, for a time budget.
+
+The `-m gpu` suite holds a fixed set of fuzz cases; this tool draws fresh ones until the budget is spent and stops at
+the first mismatch, printing the generator + seed that produced it (re-run with --only GEN --seed S).  It is a checker
+run by hand on the GPU box (the oracle is used as in tests/: never in the product path):
+
+    python tools/fuzz_gpu.py --seconds 300 [--seed 1] [--only cluster]
+
+Generators
+  cluster   junction sets that stress the sample sort and the neighbour walks: thousands of junctions sharing one
+            (chrom, left), one giant junction spanning a chromosome, nested ladders, one strand only, runs of touching
+            junctions (right == next left), sorted / reverse-sorted input order, 2 049..40 000 junctions (several buckets)
+  ps        random CSR (near + far neighbours, heavy rows) over random shapes incl. chunked widths
+  ps_f64    float64 table, sums in list order
+  ranksum   random group sizes 3..130 (lane, lane-pair, wave kernels), NaN density, quantised and raw values
+  fisher    random count rows through fisher_pairs (pair table, long walks) against scipy
+  bh        per-column sample-sort path against the generic path (bit for bit) and the oracle: tie structures,
+            sizes around the bucket limits
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import oracle_np as O  # noqa: E402
+from splicedice_amd import synth  # noqa: E402
+from splicedice_amd.engine import Context  # noqa: E402
+
+
+def gen_cluster(ctx, rng):
+    n = int(rng.choice([1, 2, 5, 300, 2049, 2500, 5000, 9000, 20000, 40000]))
+    kind = int(rng.integers(0, 8))
+    n_chrom = int(rng.choice([1, 2, 5, 30]))
+    cr = rng.integers(0, n_chrom, size=n)
+    left = rng.integers(0, max(10, n * int(rng.choice([1, 5, 50]))), size=n)
+    ln = rng.integers(1, int(rng.choice([5, 200, 20000])) + 1, size=n)
+    strand = rng.integers(0, 2, size=n)
+    if kind == 1:                                   # thousands share one (chrom, left)
+        k = min(n, int(rng.choice([600, 3000, 18000])))
+        cr[:k] = cr[0]; left[:k] = left[0]; ln[:k] = np.arange(1, k + 1)
+    elif kind == 2:                                 # one giant junction per chromosome
+        for c in range(n_chrom):
+            i = int(rng.integers(0, n))
+            cr[i] = c; left[i] = 0; ln[i] = int(left.max()) + 30000
+    elif kind == 3:                                 # nested ladder: [i, 2n - i]
+        k = min(n, 3000)
+        left[:k] = np.arange(k); ln[:k] = 2 * k - 2 * np.arange(k) + 1; cr[:k] = 0; strand[:k] = 0
+    elif kind == 4:                                 # one strand only
+        strand[:] = int(rng.integers(0, 2))
+    elif kind == 5:                                 # touching chain: right == next left
+        left = np.arange(n) * 7; ln[:] = 7; cr[:] = 0
+    elif kind == 6:                                 # few distinct lefts, many rights
+        left = rng.integers(0, 12, size=n) * 1000
+        ln = rng.integers(1, 4000, size=n)
+    key = np.unique(np.stack([cr, left, left + ln, strand], axis=1), axis=0)
+    order = int(rng.integers(0, 3))
+    if order == 0:
+        key = key[rng.permutation(len(key))]
+    elif order == 1:
+        key = key[::-1]
+    cr, left, right, strand = (np.ascontiguousarray(key[:, 0], np.int32), np.ascontiguousarray(key[:, 1], np.int32),
+                               np.ascontiguousarray(key[:, 2], np.int32), np.ascontiguousarray(key[:, 3], np.int8))
+    want = O.cluster_csr(cr, left, right, strand)
+    got = ctx.cluster(cr, left, right, strand)
+    for name, g, w in zip(("row_of", "row_ptr", "col"), got, want):
+        if not np.array_equal(g, w):
+            return f"cluster {name} differs (n={len(key)} kind={kind} order={order} n_chrom={n_chrom})"
+    return None
+
+
+def gen_ps(ctx, rng):
+    n = int(rng.choice([1, 7, 150, 900, 4000]))
+    s = int(rng.choice([1, 3, 100, 127, 129, 256, 257, 500, 1000]))
+    if n * s > 1_200_000:
+        n = max(1, 1_200_000 // s)
+    deg = rng.integers(0, 12, size=n)
+    if n > 30:
+        deg[rng.integers(0, n, size=3)] = rng.integers(17, min(n, 300) + 1, size=3)
+    row_ptr = np.r_[0, np.cumsum(deg)].astype(np.int64)
+    near = np.repeat(np.arange(n), deg) + rng.integers(-40, 41, size=int(row_ptr[-1]))
+    far = rng.integers(0, n, size=near.size)
+    col = np.clip(np.where(rng.random(near.size) < 0.85, near, far), 0, n - 1).astype(np.int32)
+    scale = int(rng.choice([1, 1, 1000, 200000]))
+    counts = (synth.make_counts(n, s, seed=int(rng.integers(1 << 30))).astype(np.int64) * scale).clip(0, (1 << 24) - 1).astype(np.int32)
+    want_ps, want_excl = O.calculate_psi_vectorised(counts, row_ptr, col)
+    ps, excl = ctx.ps(counts, row_ptr, col, want_excl=True)
+    if not np.array_equal(excl, want_excl):
+        return f"ps excl differs (n={n} s={s} scale={scale})"
+    if not np.array_equal(ps, want_ps, equal_nan=True):
+        return f"ps differs (n={n} s={s} scale={scale})"
+    return None
+
+
+def gen_ps_f64(ctx, rng):
+    n = int(rng.choice([1, 9, 200, 1500]))
+    s = int(rng.choice([1, 5, 64, 65, 200, 700]))
+    n_out = n - int(rng.integers(0, n // 3 + 1))
+    if n_out < 1:
+        n_out = n
+    deg = rng.integers(0, 14, size=n_out)
+    row_ptr = np.r_[0, np.cumsum(deg)].astype(np.int64)
+    col = rng.integers(0, n, size=int(row_ptr[-1])).astype(np.int32)
+    counts = rng.gamma(0.5, 40.0, size=(n, s)) * 10.0 ** rng.integers(-6, 7, size=(n, 1))
+    counts[rng.random((n, s)) < 0.25] = 0.0
+    want = O.write_ps_values_f64(counts, row_ptr, col, n_out)
+    got = ctx.ps_f64(counts, row_ptr, col, n_out=n_out)
+    same = np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    return None if same else f"ps_f64 differs (n={n} n_out={n_out} s={s})"
+
+
+def gen_ranksum(ctx, rng):
+    n1, n2 = int(rng.integers(3, 131)), int(rng.integers(3, 131))
+    s = n1 + n2 + int(rng.integers(0, 9))
+    n = int(rng.choice([1, 31, 32, 33, 97, 400]))
+    ps = synth.make_ps_matrix(n, s, seed=int(rng.integers(1 << 30)), nan_frac=float(rng.choice([0.0, 0.05, 0.5, 0.95])))
+    if rng.random() < 0.3:                           # raw (non-quantised) values in some rows -> redo path
+        rows = rng.integers(0, n, size=max(1, n // 5))
+        ps[rows] = rng.random((len(rows), s)).astype(np.float32)
+    if rng.random() < 0.3:
+        ps[rng.integers(0, n)] = np.float32(rng.choice([0.0, 1.0, 0.5]))
+    cols = rng.permutation(s)
+    g1, g2 = np.sort(cols[:n1]), np.sort(cols[n1:n1 + n2])
+    want = O.compare_rows(ps, g1, g2)
+    got = ctx.ranksum(ps, g1, g2)
+    tested_w = want["tested"].astype(bool)
+    if not np.array_equal(got["tested"].astype(bool), tested_w):
+        return f"ranksum tested mask differs (n={n} n1={n1} n2={n2})"
+    for k in ("med1", "med2", "mean1", "mean2", "delta", "z"):
+        if not np.array_equal(np.asarray(got[k])[tested_w], np.asarray(want[k])[tested_w]):
+            return f"ranksum {k} differs (n={n} n1={n1} n2={n2})"
+    if not np.allclose(np.asarray(got["p"])[tested_w], np.asarray(want["p"])[tested_w], rtol=1e-9, atol=0):
+        return f"ranksum p differs (n={n} n1={n1} n2={n2})"
+    return None
+
+
+def gen_fisher(ctx, rng):
+    s = int(rng.choice([2, 3, 9, 24]))
+    n = int(rng.choice([1, 17, 120]))
+    mag = int(rng.choice([3, 40, 600, 8000, 120000]))
+    incl = rng.integers(0, mag, size=(n, s)).astype(np.int32)
+    excl = rng.integers(0, mag * int(rng.choice([1, 7])), size=(n, s)).astype(np.int64)
+    z = rng.random((n, s))
+    incl[z < 0.15] = 0
+    excl[(z > 0.1) & (z < 0.25)] = 0
+    want = O.fisher_pairs(incl, excl)
+    got = ctx.fisher_pairs(incl, excl)
+    rtol = 1e-9 if mag <= 8000 else 1e-7
+    # near the underflow limit scipy's own answer is erratic (Boost's hypergeometric pmf returns spurious zeros for
+    # values of 1e-300 and below -- intermediate products underflow -- and misleads fisher_exact's boundary search:
+    # tests/test_gpu_parity.py test_fisher_p_near_underflow_is_the_exact_sum); those cells are compared by magnitude only
+    tiny = (want < 1e-280) | (got < 1e-280)
+    if (np.maximum(want, got)[tiny] > 1e-270).any():
+        return f"fisher: one side only is near the underflow limit (n={n} s={s} mag={mag})"
+    got, want = np.where(tiny, 1.0, got), np.where(tiny, 1.0, want)
+    if not np.allclose(got, want, rtol=rtol, atol=0):
+        bad = np.argwhere(~np.isclose(got, want, rtol=rtol, atol=0))[0]
+        return f"fisher differs at {tuple(bad)}: {got[tuple(bad)]!r} vs {want[tuple(bad)]!r} (n={n} s={s} mag={mag})"
+    return None
+
+
+def gen_bh(ctx, rng):
+    n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1023, 1025, 4097, 20000, 70000]))
+    cols = int(rng.choice([1, 2, 7, 8, 9, 40]))
+    if n * cols > 1_500_000:
+        cols = max(1, 1_500_000 // n)
+    p = rng.random((n, cols)) ** float(rng.choice([1, 3, 20]))
+    kind = int(rng.integers(0, 6))
+    if kind == 1:
+        p[rng.random((n, cols)) < 0.6] = 1.0
+    elif kind == 2:
+        p[:] = rng.choice([1.0, 0.5, 0.0286, 0.2, 1e-5], size=(n, cols))
+    elif kind == 3:
+        p[:, 0] = 0.125
+    elif kind == 4:
+        p[:] = 0.5 + rng.integers(0, 9, size=(n, cols)) * 2.0 ** -53
+    elif kind == 5:
+        p[:] = np.sort(p, axis=0)[::-1] if rng.random() < 0.5 else np.sort(p, axis=0)
+    try:
+        ctx.set_param("bh.columns_path", 1)
+        d = ctx.to_device(p); ctx.bh_columns_dev(d); generic = d.to_host()
+        ctx.set_param("bh.columns_path", 2)
+        d = ctx.to_device(p); ctx.bh_columns_dev(d); fast = d.to_host()
+    finally:
+        ctx.set_param("bh.columns_path", 0)
+    if not np.array_equal(generic, fast):
+        return f"bh columns: sample-sort path != generic path (n={n} cols={cols} kind={kind})"
+    if n <= 5000 and not np.allclose(fast, O.bh_columns(p), rtol=1e-14, atol=0):
+        return f"bh columns differs from the oracle (n={n} cols={cols} kind={kind})"
+    v = p[:, 0].copy()
+    if not np.allclose(ctx.bh(v), O.bh_fdr(v), rtol=1e-14, atol=0):
+        return f"bh vector differs (m={n} kind={kind})"
+    return None
+
+
+GENERATORS = {"cluster": gen_cluster, "ps": gen_ps, "ps_f64": gen_ps_f64, "ranksum": gen_ranksum, "fisher": gen_fisher,
+              "bh": gen_bh}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=None, help="progress / summary file (written as the run goes)")
+    a = ap.parse_args()
+    names = [a.only] if a.only else list(GENERATORS)
+    ctx = Context(0)
+    t0 = time.time()
+    done = {k: 0 for k in names}
+    case = 0
+    last_note = t0
+    failure = None
+    while time.time() - t0 < a.seconds:
+        name = names[case % len(names)]
+        seed = a.seed * 1_000_003 + case
+        rng = np.random.default_rng(seed)
+        with np.errstate(all="ignore"):
+            msg = GENERATORS[name](ctx, rng)
+        if msg:
+            failure = f"MISMATCH generator={name} seed={a.seed} case={case}: {msg}"
+            break
+        done[name] += 1
+        case += 1
+        if time.time() - last_note > 30:
+            last_note = time.time()
+            line = f"[{time.time() - t0:6.0f}s] " + " ".join(f"{k}={v}" for k, v in done.items())
+            print(line, flush=True)
+            if a.out:
+                with open(a.out, "a") as fh:
+                    fh.write(line + "\n")
+    ctx.close()
+    summary = failure or ("OK " + " ".join(f"{k}={v}" for k, v in done.items()) + f" cases in {time.time() - t0:.0f}s, seed {a.seed}")
+    print(summary, flush=True)
+    if a.out:
+        with open(a.out, "a") as fh:
+            fh.write(summary + "\n")
+    sys.exit(1 if failure else 0)
+
+
+if __name__ == "__main__":
+    main()
