@@ -262,3 +262,21 @@ def test_write_ps_values_f64_vs_reference_output(golden_dir):
     assert len(want) == len(order) + 1
     for r, nm in enumerate(order):
         assert want[r + 1] == nm + "\t" + "\t".join(f"{x:0.3f}" for x in ps[r])
+
+
+def test_exact_fisher_referee_vs_scipy_on_small_tables():
+    """tools/exact_fisher.py (rational arithmetic; the referee for p-values near the underflow limit, where scipy is
+    erratic) agrees with scipy where scipy is sound: small and medium tables, both sides of the mode, one-sided sums."""
+    import importlib.util
+    from scipy.stats import fisher_exact
+    spec = importlib.util.spec_from_file_location(
+        "exact_fisher", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exact_fisher.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(12)
+    tables = [(3, 1, 1, 3), (30, 12, 11, 35), (0, 5, 7, 2), (9, 0, 1, 8), (50, 50, 50, 50), (1, 200, 300, 2)]
+    tables += [tuple(int(x) for x in rng.integers(1, 400, size=4)) for _ in range(40)]
+    for a, b, c, d in tables:
+        want = fisher_exact([[a, b], [c, d]])[1]
+        got = mod.exact_two_sided(a, b, c, d)
+        assert abs(got - want) <= 1e-10 * want, (a, b, c, d, got, want)

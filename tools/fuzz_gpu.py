@@ -17,6 +17,9 @@ Generators
   fisher    random count rows through fisher_pairs (pair table, long walks) against scipy
   bh        per-column sample-sort path against the generic path (bit for bit) and the oracle: tie structures,
             sizes around the bucket limits
+  cluster_big  70 k..2.6 M skewed junctions (a tenth in one locus, 5 000 sharing one left end, unequal chromosomes):
+            the fast path against the generic radix-sort path, both on the GPU
+  chi2, quantize   --chi2 p-values against scipy; the '.3f' round trip around every rounding boundary
 """
 import argparse
 import os
@@ -73,6 +76,71 @@ def gen_cluster(ctx, rng):
     return None
 
 
+def gen_cluster_big(ctx, rng):
+    """several hundred buckets, skewed: the fast path against the generic (radix sort) path, both on the GPU"""
+    n = int(rng.choice([70_000, 300_000, 1_100_000, 2_600_000]))
+    kind = int(rng.integers(0, 5))
+    n_chrom = int(rng.choice([1, 3, 24, 400]))
+    cr = rng.integers(0, n_chrom, size=n)
+    span = n * int(rng.choice([1, 20, 400]))
+    left = rng.integers(0, span, size=n)
+    ln = rng.integers(1, int(rng.choice([30, 3000, 40000])) + 1, size=n)
+    strand = rng.integers(0, 2, size=n)
+    if kind == 1:                                   # a tenth of all junctions in one narrow locus
+        k = n // 10
+        cr[:k] = 0; left[:k] = rng.integers(1000, 1000 + max(50, k // 20), size=k); ln[:k] = rng.integers(1, 500, size=k)
+    elif kind == 2:                                 # 5 000 junctions with one (chrom, left)
+        cr[:5000] = cr[0]; left[:5000] = left[0]; ln[:5000] = np.arange(1, 5001)
+    elif kind == 3:                                 # chromosome sizes differ by 1000x
+        cr = np.minimum(cr, rng.integers(0, n_chrom, size=n)) if n_chrom > 1 else cr
+        cr[: n // 2] = 0
+    elif kind == 4:
+        strand[:] = 1
+    key = (cr.astype(np.int64) << 40) | (left.astype(np.int64) << 1) | strand
+    _, first = np.unique(np.stack([key, ln], axis=1), axis=0, return_index=True)
+    first = first[rng.permutation(first.size)]
+    cr, left, right, strand = (np.ascontiguousarray(cr[first], np.int32), np.ascontiguousarray(left[first], np.int32),
+                               np.ascontiguousarray((left + ln)[first], np.int32), np.ascontiguousarray(strand[first], np.int8))
+    fast = ctx.cluster(cr, left, right, strand)
+    try:
+        ctx.set_param("cluster.generic", 1)
+        generic = ctx.cluster(cr, left, right, strand)
+    finally:
+        ctx.set_param("cluster.generic", 0)
+    for name, g, w in zip(("row_of", "row_ptr", "col"), fast, generic):
+        if not np.array_equal(g, w):
+            return f"cluster_big {name}: fast path != generic path (n={first.size} kind={kind} n_chrom={n_chrom} span={span})"
+    return None
+
+
+def gen_chi2(ctx, rng):
+    s = int(rng.choice([2, 5, 17]))
+    n = int(rng.choice([1, 30, 200]))
+    mag = int(rng.choice([5, 80, 5000, 2_000_000]))
+    incl = rng.integers(1, mag + 1, size=(n, s)).astype(np.int32)        # (a zero expected frequency aborts the run)
+    excl = rng.integers(1, mag * int(rng.choice([1, 9])) + 1, size=(n, s)).astype(np.int64)
+    want = O.chi2_pairs(incl, excl)
+    got, bad = ctx.chi2_pairs(incl, excl)
+    want = want[0] if isinstance(want, tuple) else want
+    ok = want > 1e-290                               # (erfc / exp tails: 1e-8 as in the suite; underflowing p by magnitude)
+    if bad or not np.allclose(got[ok], want[ok], rtol=1e-8, atol=0) or (got[~ok] > 1e-280).any():
+        return f"chi2 differs (n={n} s={s} mag={mag} bad={bad})"
+    return None
+
+
+def gen_quantize(ctx, rng):
+    m = int(rng.choice([1, 1000, 300_000]))
+    x = rng.random(m).astype(np.float32)
+    k = rng.integers(0, 1001, size=m)
+    near = (k / 1000.0 + rng.choice([-1, 0, 1], size=m) * 0.0005).astype(np.float32)
+    x = np.where(rng.random(m) < 0.5, x, np.nextafter(near, np.float32(rng.choice([0.0, 1.0]))))
+    x[rng.random(m) < 0.05] = np.nan
+    want = O.quantize3(x)
+    got = ctx.quantize3(x.copy())
+    same = np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    return None if same else f"quantize3 differs (m={m})"
+
+
 def gen_ps(ctx, rng):
     n = int(rng.choice([1, 7, 150, 900, 4000]))
     s = int(rng.choice([1, 3, 100, 127, 129, 256, 257, 500, 1000]))
@@ -115,8 +183,15 @@ def gen_ps_f64(ctx, rng):
 
 def gen_ranksum(ctx, rng):
     n1, n2 = int(rng.integers(3, 131)), int(rng.integers(3, 131))
-    s = n1 + n2 + int(rng.integers(0, 9))
     n = int(rng.choice([1, 31, 32, 33, 97, 400]))
+    u = rng.random()
+    if u < 0.2:                                      # counting / wave kernels (65..1024), block kernel beyond
+        n1, n2 = int(rng.integers(3, 1100)), int(rng.integers(60, 1100))
+        n = int(rng.choice([1, 9, 40]))
+    elif u < 0.27:
+        n1, n2 = int(rng.integers(1000, 4097)), int(rng.integers(3, 4097))
+        n = int(rng.choice([1, 7]))
+    s = n1 + n2 + int(rng.integers(0, 9))
     ps = synth.make_ps_matrix(n, s, seed=int(rng.integers(1 << 30)), nan_frac=float(rng.choice([0.0, 0.05, 0.5, 0.95])))
     if rng.random() < 0.3:                           # raw (non-quantised) values in some rows -> redo path
         rows = rng.integers(0, n, size=max(1, n // 5))
@@ -198,7 +273,7 @@ def gen_bh(ctx, rng):
 
 
 GENERATORS = {"cluster": gen_cluster, "ps": gen_ps, "ps_f64": gen_ps_f64, "ranksum": gen_ranksum, "fisher": gen_fisher,
-              "bh": gen_bh}
+              "bh": gen_bh, "cluster_big": gen_cluster_big, "chi2": gen_chi2, "quantize": gen_quantize}
 
 
 def main():
