@@ -3,9 +3,9 @@
 
 The `-m gpu` suite holds a fixed set of fuzz cases; this tool draws fresh ones until the budget is spent and stops at
 the first mismatch, printing the generator + seed that produced it (re-run with --only GEN --seed S).  It is a checker
-run by hand on the GPU box (the oracle is used as in tests/: never in the product path):
+run by hand on the GPU box; it lives under tests/ because it uses the oracle (test infrastructure), like the suite:
 
-    python tools/fuzz_gpu.py --seconds 300 [--seed 1] [--only cluster]
+    python tests/fuzz_gpu.py --seconds 300 [--seed 1] [--only cluster]
 
 Generators
   cluster   junction sets that stress the sample sort and the neighbour walks: thousands of junctions sharing one

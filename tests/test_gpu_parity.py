@@ -738,7 +738,7 @@ def test_fisher_p_near_underflow_is_the_exact_sum(ctx, table, want, scipy_says):
     table: pmf(48545) = 1.0e-300, pmf(48546) = 0, pmf(48547) = 1.8e-300), fisher_exact's boundary search is misled and
     the far tail drops out of the sum (scipy 1.15.3 returns `scipy_says`, the near tail alone) -- while the kernel's
     ratio walk never leaves the normal range until the final product.  The kernel returns the EXACT two-sided sum:
-    `want` comes from rational arithmetic (tools/exact_fisher.py, ~5 min per table; both found by tools/fuzz_gpu.py)."""
+    `want` comes from rational arithmetic (tools/exact_fisher.py, ~5 min per table; both found by tests/fuzz_gpu.py)."""
     a, b, c, d = table
     got = ctx.fisher_tables(np.array([table], np.int64))[0]
     assert abs(got - want) <= 1e-7 * want                    # (pmf(a) = exp of nine log-factorials of ~6e6: ~1e-9)
