@@ -351,6 +351,7 @@ constexpr unsigned char RS_REDO_Q = 0xFF;       // (same mark as RS_REDO below)
 constexpr int RSQ_G2 = 64;                      // u16 offset of group 2 inside a staged row
 constexpr int RSQ_STRIDE = 130;                 // u16 per staged row: 65 dwords
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+typedef uint32_t __attribute__((may_alias)) u32_alias;      // dword view of the staged 16-bit keys
 
 __device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
     union { uint32_t u; v2u16 v; } x, y, r;
@@ -415,6 +416,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     unsigned short* tile = reinterpret_cast<unsigned short*>(selL + ((nsel + 1) & ~1)) + (size_t)wave * 32 * stride;
     for (int k = threadIdx.x; k < 1008; k += blockDim.x) T[k] = (float)((double)k / 1000.0);
     for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    // every slot of the tile starts as 0xFFFF ("no value"): the staging only ever writes the first n1 / n2 slots of a
+    // group and the sorted write-back leaves 0xFFFF in the others, so the slots behind a group never need a bound check
+    for (int k = lane; k < 16 * stride; k += 64) reinterpret_cast<u32_alias*>(tile)[k] = 0xFFFFFFFFu;
     __syncthreads();
     const int64_t n_groups = (n + 31) >> 5;
     for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
@@ -465,28 +469,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         const int r = lane >> 1, grp = lane & 1;
         unsigned short* row = tile + r * stride;
         unsigned short* grow = row + (grp ? RSQ_G2 : 0);
-        const int cnt = grp ? n2 : n1;
         // ---- compaction (NaNs dropped, order kept) through LDS, then the keys of this group in registers
         int nv = 0;
 #pragma unroll
-        for (int e0 = 0; e0 < P; e0 += 16) {       // 16 reads in flight, then their compacting stores (all to indices <= e)
-            unsigned short v[16];
+        for (int e0 = 0; e0 < P; e0 += 16) {       // 8 dword reads (16 keys) in flight, then their compacting stores (all to indices <= e)
+            uint32_t w[8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = e0 + e < cnt ? grow[e0 + e] : (unsigned short)0xFFFF;
+            for (int k = 0; k < 8; ++k) w[k] = reinterpret_cast<const u32_alias*>(grow)[e0 / 2 + k];
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (v[e] != 0xFFFF) { grow[nv] = v[e]; ++nv; }
+            for (int e = 0; e < 16; ++e) {
+                const unsigned short v = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+                if (v != 0xFFFF) { grow[nv] = v; ++nv; }
+            }
         }
+        // one dword = two compacted keys: the sorting network takes its input in any order, so dword d (values 2d and
+        // 2d + 1) goes straight to register d (32 LDS reads instead of 64); entries behind the last value become 0xFFFF
         uint32_t key[NR];
+        {
+            const u32_alias* grow32 = reinterpret_cast<const u32_alias*>(grow);
 #pragma unroll
-        for (int a = 0; a < NR; ++a) {
-            const uint32_t lo = a < nv ? grow[a] : 0xFFFFu, hi = a + NR < nv ? grow[a + NR] : 0xFFFFu;
-            key[a] = lo | (hi << 16);
+            for (int d = 0; d < NR; ++d) {
+                uint32_t v = grow32[d];
+                v = 2 * d + 1 < nv ? v : (v | 0xFFFF0000u);
+                key[d] = 2 * d < nv ? v : 0xFFFFFFFFu;
+            }
         }
         // ---- numpy pairwise_sum over T[key] in original order (n <= 128 -> single block), npy loops_utils.h.src
         float mean;
         {
-            auto val = [&](int e) -> float { return T[e < NR ? (key[e] & 0xffffu) : (key[e - NR] >> 16)]; };   // (only read for e < nv)
+            auto val = [&](int e) -> float { return T[(e & 1) ? (key[e >> 1] >> 16) : (key[e >> 1] & 0xffffu)]; };   // (only read for e < nv)
             float res;
             if (nv < 8) {
                 res = 0.f;
@@ -509,12 +520,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             mean = nv > 0 ? res / (float)nv : 0.f;
         }
         sort_keys16<P>(key);
+        // sorted: rank i sits in the low half of key[i] (i < NR), rank i + NR in the high half of key[i].  Back to LDS as
+        // 32 dwords (rank 2d | rank 2d + 1 << 16, one v_perm each) instead of 64 16-bit stores; all 64 slots of the
+        // group are written, the padding (0xFFFF, ranks >= nv) is the sentinel behind the values (n1, n2 <= 63)
+        {
+            u32_alias* grow32 = reinterpret_cast<u32_alias*>(grow);
 #pragma unroll
-        for (int a = 0; a < NR; ++a) {
-            if (a < cnt) grow[a] = (unsigned short)(key[a] & 0xffffu);
-            if (a + NR < cnt) grow[a + NR] = (unsigned short)(key[a] >> 16);
+            for (int d = 0; d < NR; ++d) {
+                const int i0 = 2 * d, i1 = 2 * d + 1;
+                grow32[d] = i1 < NR ? __builtin_amdgcn_perm(key[i1], key[i0], 0x05040100u)
+                                    : __builtin_amdgcn_perm(key[i1 - NR], key[i0 - NR], 0x07060302u);
+            }
         }
-        grow[cnt] = (unsigned short)0xFFFF;      // sentinel behind the group (n1 <= 63: still inside its 64 slots)
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();          // the partner's sorted group is in LDS
         const int nv_other = __shfl_xor(nv, 1);

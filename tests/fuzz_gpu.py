@@ -35,6 +35,15 @@ from splicedice_amd import synth  # noqa: E402
 from splicedice_amd.engine import Context  # noqa: E402
 
 
+def expected_nnz(cr, left, right, strand):
+    """number of neighbour-list entries of a junction set (two per overlapping pair), without building the lists"""
+    g = cr.astype(np.int64) * 2 + strand
+    o = np.lexsort((left, g))
+    key = (g[o] << 40) + left[o]
+    ub = np.searchsorted(key, (g[o] << 40) + right[o], side="right")
+    return 2 * int((ub - np.arange(len(o)) - 1).sum())
+
+
 def gen_cluster(ctx, rng):
     n = int(rng.choice([1, 2, 5, 300, 2049, 2500, 5000, 9000, 20000, 40000]))
     kind = int(rng.integers(0, 8))
@@ -68,6 +77,8 @@ def gen_cluster(ctx, rng):
         key = key[::-1]
     cr, left, right, strand = (np.ascontiguousarray(key[:, 0], np.int32), np.ascontiguousarray(key[:, 1], np.int32),
                                np.ascontiguousarray(key[:, 2], np.int32), np.ascontiguousarray(key[:, 3], np.int8))
+    if expected_nnz(cr, left, right, strand) > 20_000_000:      # (the oracle holds the lists as Python objects)
+        return None
     want = O.cluster_csr(cr, left, right, strand)
     got = ctx.cluster(cr, left, right, strand)
     for name, g, w in zip(("row_of", "row_ptr", "col"), got, want):
@@ -101,6 +112,8 @@ def gen_cluster_big(ctx, rng):
     first = first[rng.permutation(first.size)]
     cr, left, right, strand = (np.ascontiguousarray(cr[first], np.int32), np.ascontiguousarray(left[first], np.int32),
                                np.ascontiguousarray((left + ln)[first], np.int32), np.ascontiguousarray(strand[first], np.int8))
+    if expected_nnz(cr, left, right, strand) > 400_000_000:     # (a dense draw: 2.6 M junctions of up to 40 kb inside 2.6 Mb
+        return None                                             #  would be 5e10 list entries, 200 GB on the host)
     fast = ctx.cluster(cr, left, right, strand)
     try:
         ctx.set_param("cluster.generic", 1)
@@ -276,24 +289,64 @@ GENERATORS = {"cluster": gen_cluster, "ps": gen_ps, "ps_f64": gen_ps_f64, "ranks
               "bh": gen_bh, "cluster_big": gen_cluster_big, "chi2": gen_chi2, "quantize": gen_quantize}
 
 
+def rss_gib():
+    with open("/proc/self/status") as fh:
+        for line in fh:
+            if line.startswith("VmRSS:"):
+                return int(line.split()[1]) / (1 << 20)
+    return 0.0
+
+
+CURRENT = {"what": "start"}
+
+
+def watchdog(limit_gib, out):
+    """a case that runs away with host memory ends the process here (exit code 3), long before the box's cap does"""
+    import threading
+
+    def loop():
+        while True:
+            time.sleep(0.1)
+            g = rss_gib()
+            if g > limit_gib:
+                msg = f"RSS {g:.1f} GiB > {limit_gib} GiB during {CURRENT['what']}: aborting"
+                print(msg, flush=True)
+                if out:
+                    with open(out, "a") as fh:
+                        fh.write(msg + "\n")
+                os._exit(3)
+    threading.Thread(target=loop, daemon=True).start()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", default=None)
     ap.add_argument("--out", default=None, help="progress / summary file (written as the run goes)")
+    ap.add_argument("--verbose", action="store_true", help="one line per case (with the resident set size)")
+    ap.add_argument("--first-case", type=int, default=0)
+    ap.add_argument("--rss-limit-gib", type=float, default=40.0)
     a = ap.parse_args()
+    watchdog(a.rss_limit_gib, a.out)
     names = [a.only] if a.only else list(GENERATORS)
     ctx = Context(0)
     t0 = time.time()
     done = {k: 0 for k in names}
-    case = 0
+    case = a.first_case
     last_note = t0
     failure = None
     while time.time() - t0 < a.seconds:
         name = names[case % len(names)]
         seed = a.seed * 1_000_003 + case
         rng = np.random.default_rng(seed)
+        CURRENT["what"] = f"generator={name} seed={a.seed} case={case}"
+        if a.verbose:
+            line = f"case {case} {name} rss {rss_gib():.2f} GiB"
+            print(line, flush=True)
+            if a.out:
+                with open(a.out, "a") as fh:
+                    fh.write(line + "\n")
         with np.errstate(all="ignore"):
             msg = GENERATORS[name](ctx, rng)
         if msg:
