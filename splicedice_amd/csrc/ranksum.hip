@@ -366,6 +366,14 @@ __device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b) {
     return r.u;
 }
 __device__ __forceinline__ uint32_t swap16(uint32_t a) { return (a >> 16) | (a << 16); }
+// float32(k / 1000.0) for k = 0..1000 without the table: the product with float32(0.001) plus one residual step is
+// the correctly rounded quotient for every one of the 1001 values (checked exhaustively against the table's
+// definition, tests/test_abi_and_host.py) -- three VALU instructions instead of an LDS look-up, which is what this
+// kernel is short of
+__device__ __forceinline__ float ps_of_key(float kf) {
+    const float q = kf * 0.001f;
+    return __builtin_fmaf(__builtin_fmaf(-q, 1000.0f, kf), 0.001f, q);
+}
 __device__ __forceinline__ uint32_t lo_hi(uint32_t lo_from, uint32_t hi_from) { return (lo_from & 0xffffu) | (hi_from & 0xffff0000u); }
 
 // ascending sort of P 16-bit keys, k[r] = element r | element (r + P/2) << 16  (flip + disperse network)
@@ -454,10 +462,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const bool live = r < rows_avail;
                     // key of a value: k = rint(1000 x) when x == T[k] exactly, 0xFFFF for NaN (and rows past the end)
                     const float a0 = x0[q], a1 = x1[q];
-                    const int k0 = min(max((int)__builtin_rintf(a0 * 1000.0f), 0), 1000);
-                    const int k1 = min(max((int)__builtin_rintf(a1 * 1000.0f), 0), 1000);
+                    const float kf0 = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(a0 * 1000.0f), 0.0f), 1000.0f);     // (NaN -> 0)
+                    const float kf1 = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(a1 * 1000.0f), 0.0f), 1000.0f);
+                    const int k0 = (int)kf0, k1 = (int)kf1;
                     const bool nan0 = !(a0 == a0) || !live, nan1 = !(a1 == a1) || !live;
-                    const bool bad0 = act0 && !nan0 && T[k0] != a0, bad1 = act1 && !nan1 && T[k1] != a1;
+                    const bool bad0 = act0 && !nan0 && ps_of_key(kf0) != a0, bad1 = act1 && !nan1 && ps_of_key(kf1) != a1;
                     if (__ballot(bad0 || bad1)) redo_rows |= 1u << r;
                     if (act0) tile[r * stride + pos0] = nan0 ? (unsigned short)0xFFFF : (unsigned short)k0;
                     if (act1) tile[r * stride + pos1] = nan1 ? (unsigned short)0xFFFF : (unsigned short)k1;

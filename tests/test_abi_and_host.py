@@ -425,3 +425,32 @@ def test_annotation_columns_against_reference_table(golden_dir, tmp_path, gtf, t
     textio.write_columns(out, "event\tx\tgene\toverlapping\ttranscript_id\n", names, [x], ["repr"], suffixes=sfx)
     got = out.read_text().splitlines()
     assert got[1:] == [f"{nm}\t{str(np.float64(v))}{s}" for nm, v, s in zip(names, x, sfx)]
+
+
+def test_ps_of_key_formula_reproduces_the_table():
+    """ranksum.hip ps_of_key(): q = k * 0.001f; q = fma(fma(-q, 1000, k), 0.001f, q) must equal float32(k / 1000.0)
+    (the '.3f' text read back as float32, compareSampleSets.py:202) for every k = 0..1000 -- exact rational
+    arithmetic with one correct rounding per float32 operation."""
+    from fractions import Fraction
+
+    def rn32(x):                                  # round-to-nearest-even of a Fraction to float32
+        if x == 0:
+            return np.float32(0)
+        f = np.float32(float(x))
+        best = None
+        for c in (np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))):
+            d = abs(Fraction(float(c)) - x)
+            even = (int(np.float32(c).view(np.uint32)) & 1) == 0
+            if best is None or d < best[0] or (d == best[0] and even):
+                best = (d, c)
+        return np.float32(best[1])
+
+    def fr(v):
+        return Fraction(float(v))
+    c001, c1000 = np.float32(0.001), np.float32(1000.0)
+    for k in range(1001):
+        kf = np.float32(k)
+        q = rn32(fr(kf) * fr(c001))
+        r = rn32(-fr(q) * fr(c1000) + fr(kf))
+        q = rn32(fr(r) * fr(c001) + fr(q))
+        assert q == np.float32(np.float64(k) / 1000.0), k
