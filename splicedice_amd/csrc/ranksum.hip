@@ -506,7 +506,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         // ---- numpy pairwise_sum over T[key] in original order (n <= 128 -> single block), npy loops_utils.h.src
         float mean;
         {
-            auto val = [&](int e) -> float { return T[(e & 1) ? (key[e >> 1] >> 16) : (key[e >> 1] & 0xffffu)]; };   // (only read for e < nv)
+            // (only read for e < nv; float32(k / 1000) by arithmetic, not from the table: LDS instructions are what the kernel is short of)
+            auto val = [&](int e) -> float { return ps_of_key((float)((e & 1) ? (key[e >> 1] >> 16) : (key[e >> 1] & 0xffffu))); };
             float res;
             if (nv < 8) {
                 res = 0.f;
