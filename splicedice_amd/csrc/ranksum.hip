@@ -344,9 +344,9 @@ __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restri
 //     register i mod P/2, element i + P/2 in the high half -- with v_pk_min_u16 / v_pk_max_u16: one
 //     instruction pair exchanges two comparators, half the instructions of the float network (only
 //     the flip of the last merge crosses the halves and costs six instructions per register pair);
-//   * floats come back through the table T[k] = float32(k / 1000): the numpy pairwise sum runs over
-//     T[key] in original order, medians are T[key] of the middle keys.
-// A row holding any value that is not exactly T[k] is marked RS_REDO and left to ranksum_wave_kernel.
+//   * floats come back as float32(k / 1000), computed (ps_of_key: no table, LDS instructions are the scarce resource
+//     here): the numpy pairwise sum runs over them in original order, medians are those of the middle keys.
+// A row holding any value that is not exactly float32(k / 1000) is marked RS_REDO and left to ranksum_wave_kernel.
 constexpr unsigned char RS_REDO_Q = 0xFF;       // (same mark as RS_REDO below)
 constexpr int RSQ_G2 = 64;                      // u16 offset of group 2 inside a staged row
 constexpr int RSQ_STRIDE = 130;                 // u16 per staged row: 65 dwords
@@ -419,10 +419,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     const int nsel = n1 + n2;
-    float* T = smemq;                                                   // [1008] float32(k / 1000)
-    int* selL = reinterpret_cast<int*>(smemq + 1008);                   // [nsel]
+    int* selL = reinterpret_cast<int*>(smemq);                          // [nsel]
     unsigned short* tile = reinterpret_cast<unsigned short*>(selL + ((nsel + 1) & ~1)) + (size_t)wave * 32 * stride;
-    for (int k = threadIdx.x; k < 1008; k += blockDim.x) T[k] = (float)((double)k / 1000.0);
     for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
     // every slot of the tile starts as 0xFFFF ("no value"): the staging only ever writes the first n1 / n2 slots of a
     // group and the sorted write-back leaves 0xFFFF in the others, so the slots behind a group never need a bound check
@@ -460,7 +458,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                 for (int q = 0; q < RB; ++q) {
                     const int r = r0 + q;
                     const bool live = r < rows_avail;
-                    // key of a value: k = rint(1000 x) when x == T[k] exactly, 0xFFFF for NaN (and rows past the end)
+                    // key of a value: k = rint(1000 x) when x == float32(k / 1000) exactly, 0xFFFF for NaN (and rows past the end)
                     const float a0 = x0[q], a1 = x1[q];
                     const float kf0 = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(a0 * 1000.0f), 0.0f), 1000.0f);     // (NaN -> 0)
                     const float kf1 = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(a1 * 1000.0f), 0.0f), 1000.0f);
@@ -503,7 +501,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                 key[d] = 2 * d < nv ? v : 0xFFFFFFFFu;
             }
         }
-        // ---- numpy pairwise_sum over T[key] in original order (n <= 128 -> single block), npy loops_utils.h.src
+        // ---- numpy pairwise_sum over float32(key / 1000) in original order (n <= 128 -> single block), npy loops_utils.h.src
         float mean;
         {
             // (only read for e < nv; float32(k / 1000) by arithmetic, not from the table: LDS instructions are what the kernel is short of)
@@ -554,7 +552,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         if (tested) {
             const unsigned short* G = grp ? B : A;
             const int h = nv >> 1;
-            med = (nv & 1) ? T[G[h]] : (T[G[h - 1]] + T[G[h]]) / 2.0f;      // np.median on float32
+            med = (nv & 1) ? ps_of_key((float)G[h]) : (ps_of_key((float)G[h - 1]) + ps_of_key((float)G[h])) / 2.0f;      // np.median on float32
             // one merge walk; positions nv1 of A and nv2 of B hold 0xFFFF (the sorted padding or the sentinel), so an
             // exhausted side loses every comparison and no index has to be checked or clamped.  The even lane
             // counts "b <= a" (upper bounds), the odd lane "b < a": b goes first when b < a + adj.
@@ -1075,7 +1073,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
                 const float kf = rintf(v * 1000.0f);
                 const bool inr = kf >= 0.0f && kf <= 1000.0f;        // false for NaN
                 const int k = inr ? (int)kf : 0;
-                ok = ok && (v != v || (inr && T[k] == v));
+                ok = ok && (v != v || (inr && ps_of_key(kf) == v));          // (arithmetic, not T[k]: one LDS look-up fewer)
                 packed_k = (v != v) ? 0u : (unsigned)(k + 1);
             }
             {
@@ -1083,7 +1081,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
                 const float kf = rintf(v * 1000.0f);
                 const bool inr = kf >= 0.0f && kf <= 1000.0f;
                 const int k = inr ? (int)kf : 0;
-                ok = ok && (v != v || (inr && T[k] == v));
+                ok = ok && (v != v || (inr && ps_of_key(kf) == v));
                 packed_k |= (v != v) ? 0u : ((unsigned)(k + 1) << 16);
             }
             kk[e] = packed_k;
@@ -1305,7 +1303,7 @@ int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int3
     const int stride = RSQ_STRIDE;                         // u16 units (n1, n2 <= 64)
     const int waves = 4;
     const int nsel = n1 + n2;
-    const size_t lds = (size_t)1008 * 4 + (size_t)((nsel + 1) & ~1) * 4 + (size_t)waves * 32 * stride * 2;
+    const size_t lds = (size_t)((nsel + 1) & ~1) * 4 + (size_t)waves * 32 * stride * 2;
     int64_t blocks = sd_ceil_div(sd_ceil_div(n, 32), waves);
     const int64_t cap = (int64_t)ctx->n_cu * 16;
     if (blocks > cap) blocks = cap;
