@@ -999,6 +999,46 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
     }
 }
 
+// The same sums for TWO arrays of at most 512 values each (at most 8 leaves each) in one pass: lanes 0..31 work on A,
+// lanes 32..63 on B, four leaves per half and round -- half the LDS instructions of two calls (the counting kernel
+// issues most of its LDS instructions here).
+__device__ __forceinline__ void wave_pairwise_sum2(const float* CA, int nvA, const float* CB, int nvB, int lane, int* leaf_off /* [18] */,
+                                                   float* leaf_sum /* [16] */, float& sumA, float& sumB) {
+    const bool second = lane >= 32;
+    const float* C = second ? CB : CA;
+    const int nv = second ? nvB : nvA;
+    int* lo = leaf_off + (second ? 9 : 0);
+    float* ls = leaf_sum + (second ? 8 : 0);
+    int nl = 0;
+    pw_leaves<PW_WAVE_DEPTH>(0, nv, lo, nl, (lane & 31) == 0);
+    if ((lane & 31) == 0) lo[nl] = nv;
+    SD_WAVE_SYNC();
+    const int nl_max = max(__shfl(nl, 0), __shfl(nl, 32));
+    const int j = lane & 7;
+    for (int base = 0; base < nl_max; base += 4) {      // wave-uniform trip count
+        const int L = base + ((lane >> 3) & 3);
+        int off = 0, len = 0;
+        if (L < nl) { off = lo[L]; len = lo[L + 1] - off; }
+        const int main_n = len - (len & 7);
+        float r = 0.f;
+        if (len >= 8) {
+            r = C[off + j];
+            for (int i = 8; i < main_n; i += 8) r += C[off + i + j];
+        }
+        r = r + __shfl_xor(r, 1);
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        for (int i = (len >= 8 ? main_n : 0); i < len; ++i) r += C[off + i];
+        if (j == 0 && L < nl) ls[L] = r;
+    }
+    SD_WAVE_SYNC();
+    int next = 0;
+    const float out = pw_combine<PW_WAVE_DEPTH>(nv, ls, next);
+    SD_WAVE_SYNC();
+    sumA = __shfl(out, 0);
+    sumB = __shfl(out, 32);
+}
+
 // ------------------------------------------------------------------ counting variant (quantised PS)
 // compare_sample_sets always sees PS values that went through the '.3f' text of _allPS.tsv
 // (SPLICEDICE.py:353 -> compareSampleSets.py:202), i.e. float32(k / 1000.0) for k = 0..1000: a row's
@@ -1029,14 +1069,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
     constexpr int WSTRIDE = 2 * N + 40 + (H_ALIAS ? 0 : RS_BINS) + 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
-    float* T = smemc;                                          // T[k] = float32(k / 1000.0), shared by the block
-    float* SA = smemc + 1008 + (size_t)wave * WSTRIDE;
+    float* SA = smemc + (size_t)wave * WSTRIDE;
     float* SB = SA + N;
     float* leaf_sum = SB + N;
     int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);
     unsigned* H = H_ALIAS ? reinterpret_cast<unsigned*>(SA) : reinterpret_cast<unsigned*>(SB + N + 40);    // [RS_BINS] a_v | b_v << 16
-    for (int k = threadIdx.x; k < 1008; k += blockDim.x) T[k] = (float)((double)k / 1000.0);
-    __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int idx1[E], idx2[E];
 #pragma unroll
@@ -1113,8 +1150,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
             if (lane == ri) { s_nv1 = nv1; s_nv2 = nv2; }
             continue;
         }
-        const float sum1 = wave_pairwise_sum(SA, nv1, lane, leaf_off, leaf_sum);
-        const float sum2 = wave_pairwise_sum(SB, nv2, lane, leaf_off, leaf_sum);
+        float sum1, sum2;
+        if (E <= 8) {
+            wave_pairwise_sum2(SA, nv1, SB, nv2, lane, leaf_off, leaf_sum, sum1, sum2);
+        } else {
+            sum1 = wave_pairwise_sum(SA, nv1, lane, leaf_off, leaf_sum);
+            sum2 = wave_pairwise_sum(SB, nv2, lane, leaf_off, leaf_sum);
+        }
         if (H_ALIAS) {
             SD_WAVE_SYNC();                 // every lane has read its values
 #pragma unroll
@@ -1193,7 +1235,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
         const int binA0 = (nv1 & 1) ? binA1 : find_bin(hA - 1, false);      // wave-uniform branches
         const int binB0 = (nv2 & 1) ? binB1 : find_bin(hB - 1, true);
         // np.median: odd -> middle value; even -> (v[h-1] + v[h]) / 2 in float32
-        const float a0 = T[binA0], a1 = T[binA1], b0 = T[binB0], b1 = T[binB1];
+        const float a0 = ps_of_key((float)binA0), a1 = ps_of_key((float)binA1), b0 = ps_of_key((float)binB0), b1 = ps_of_key((float)binB1);
         const float med1 = (nv1 & 1) ? a1 : (a0 + a1) / 2.0f;
         const float med2 = (nv2 & 1) ? b1 : (b0 + b1) / 2.0f;
         if (lane == ri) {
@@ -1248,7 +1290,7 @@ int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     if (blocks > cap) blocks = cap;
     if (counting) {
         // histogram path for rows of 3-decimal PS values; the sorting kernel then takes the rows it marked
-        const size_t lds_c = (size_t)(1008 + waves * (2 * 64 * E + 40 + (2 * 64 * E >= RS_BINS ? 0 : RS_BINS) + 8)) * 4;
+        const size_t lds_c = (size_t)(waves * (2 * 64 * E + 40 + (2 * 64 * E >= RS_BINS ? 0 : RS_BINS) + 8)) * 4;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_count_kernel<E>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         SD_LAUNCH(ctx, "ranksum_count_kernel", (ranksum_count_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds_c,
