@@ -431,18 +431,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
          g += (int64_t)gridDim.x * waves_per_block) {
         const int64_t row0 = g << 5;
         unsigned redo_rows = 0;                        // bit r: row r holds a value that is not a 3-decimal PS
-        {   // stage 32 rows x nsel selected columns as keys (lane l owns selected columns l and l + 64)
+        {   // stage 32 rows x nsel selected columns as keys: lanes 0..31 own group 1's columns (2l, 2l + 1), lanes 32..63
+            // group 2's -- the two keys of a lane are ONE dword of the row (dword index = lane: one conflict-free
+            // 32-bit store per row and lane instead of two 16-bit stores; slots behind the group get 0xFFFF)
             const int rows_avail = (int)min((int64_t)32, n - row0);
             const float* gbase = ps + row0 * s;
-            const bool act0 = lane < nsel, act1 = lane + 64 < nsel;
-            const int sel0 = act0 ? selL[lane] : 0;
-            const int sel1 = act1 ? selL[lane + 64] : 0;
+            const int e0 = 2 * (lane & 31), e1 = e0 + 1;
+            const int cntg = lane >= 32 ? n2 : n1, selbase = lane >= 32 ? n1 : 0;
+            const bool act0 = e0 < cntg, act1 = e1 < cntg;
+            const int sel0 = act0 ? selL[selbase + e0] : 0;
+            const int sel1 = act1 ? selL[selbase + e1] : 0;
+            u32_alias* tile32 = reinterpret_cast<u32_alias*>(tile);
+            const int pitch32 = stride >> 1;
             // group 1 at the start of the row, group 2 at u16 offset 64: with a row pitch of 65 dwords the 32 rows x 2
             // groups of a wave sit in 64 different banks (r and r + 32) whenever the lanes read the same element
             // index -- the packed layout (group 2 right behind group 1, odd pitch) lost 47 % of its LDS cycles to
             // bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
-            const int pos0 = lane < n1 ? lane : RSQ_G2 + lane - n1;
-            const int pos1 = lane + 64 < n1 ? lane + 64 : RSQ_G2 + lane + 64 - n1;
             constexpr int RB = 16;
             for (int r0 = 0; r0 < 32; r0 += RB) {
                 float x0[RB], x1[RB];
@@ -466,8 +470,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const bool nan0 = !(a0 == a0) || !live, nan1 = !(a1 == a1) || !live;
                     const bool bad0 = act0 && !nan0 && ps_of_key(kf0) != a0, bad1 = act1 && !nan1 && ps_of_key(kf1) != a1;
                     if (__ballot(bad0 || bad1)) redo_rows |= 1u << r;
-                    if (act0) tile[r * stride + pos0] = nan0 ? (unsigned short)0xFFFF : (unsigned short)k0;
-                    if (act1) tile[r * stride + pos1] = nan1 ? (unsigned short)0xFFFF : (unsigned short)k1;
+                    const uint32_t kk0 = (act0 && !nan0) ? (uint32_t)k0 : 0xFFFFu, kk1 = (act1 && !nan1) ? (uint32_t)k1 : 0xFFFFu;
+                    tile32[r * pitch32 + lane] = kk0 | (kk1 << 16);
                 }
             }
         }
