@@ -777,6 +777,11 @@ __global__ void __launch_bounds__(RB_THREADS) ranksum_block_kernel(const float* 
     }
 }
 
+// number of set bits of a wave mask below this lane (v_mbcnt_lo + v_mbcnt_hi: two instructions, no 64-bit mask per lane)
+__device__ __forceinline__ int lanes_below(unsigned long long m, int base = 0) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)base));
+}
+
 // ------------------------------------------------------------------ wave-per-row variant
 // 64 < max(n1, n2) <= 64*E: one WAVE per row, E values of a group per lane, no workgroup
 // barrier anywhere.  The sort is a bitonic network over 64*E elements in "blocked" layout
@@ -881,7 +886,6 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
     float* leaf_sum = SB + N;                                  // [<= 16]
     int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);     // [<= 17]
     const float inf = __builtin_inff();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // the selected columns of this lane (striped: selection k = e*64 + lane), loaded once
     int idx1[E], idx2[E];
 #pragma unroll
@@ -922,11 +926,11 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
         for (int e = 0; e < E; ++e) {
             const bool v1 = x[e] == x[e];
             const unsigned long long m1 = __ballot(v1);
-            if (v1) SA[nv1 + __popcll(m1 & lt_mask)] = x[e];
+            if (v1) SA[lanes_below(m1, nv1)] = x[e];
             nv1 += __popcll(m1);
             const bool v2 = y[e] == y[e];
             const unsigned long long m2 = __ballot(v2);
-            if (v2) SB[nv2 + __popcll(m2 & lt_mask)] = y[e];
+            if (v2) SB[lanes_below(m2, nv2)] = y[e];
             nv2 += __popcll(m2);
         }
         SD_WAVE_SYNC();
@@ -1078,7 +1082,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
     float* leaf_sum = SB + N;
     int* leaf_off = reinterpret_cast<int*>(leaf_sum + 16);
     unsigned* H = H_ALIAS ? reinterpret_cast<unsigned*>(SA) : reinterpret_cast<unsigned*>(SB + N + 40);    // [RS_BINS] a_v | b_v << 16
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int idx1[E], idx2[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1137,11 +1140,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
         for (int e = 0; e < E; ++e) {
             const bool v1 = (kk[e] & 0xffffu) != 0u;
             const unsigned long long m1 = __ballot(v1);
-            if (v1) SA[nv1 + __popcll(m1 & lt_mask)] = x[e];
+            if (v1) SA[lanes_below(m1, nv1)] = x[e];
             nv1 += __popcll(m1);
             const bool v2 = (kk[e] >> 16) != 0u;
             const unsigned long long m2 = __ballot(v2);
-            if (v2) SB[nv2 + __popcll(m2 & lt_mask)] = y[e];
+            if (v2) SB[lanes_below(m2, nv2)] = y[e];
             nv2 += __popcll(m2);
         }
         // clear the histogram: 16 words per lane (when it shares the SA | SB area: after the sums)
