@@ -464,8 +464,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const bool live = r < rows_avail;
                     // key of a value: k = rint(1000 x) when x == float32(k / 1000) exactly, 0xFFFF for NaN (and rows past the end)
                     const float a0 = x0[q], a1 = x1[q];
-                    const float kf0 = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(a0 * 1000.0f), 0.0f), 1000.0f);     // (NaN -> 0)
-                    const float kf1 = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(a1 * 1000.0f), 0.0f), 1000.0f);
+                    const float kf0 = __builtin_amdgcn_fmed3f(__builtin_rintf(a0 * 1000.0f), 0.0f, 1000.0f);     // (a NaN's key is never used)
+                    const float kf1 = __builtin_amdgcn_fmed3f(__builtin_rintf(a1 * 1000.0f), 0.0f, 1000.0f);
                     const int k0 = (int)kf0, k1 = (int)kf1;
                     const bool nan0 = !(a0 == a0) || !live, nan1 = !(a1 == a1) || !live;
                     const bool bad0 = act0 && !nan0 && ps_of_key(kf0) != a0, bad1 = act1 && !nan1 && ps_of_key(kf1) != a1;
@@ -1113,19 +1113,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
         for (int e = 0; e < E; ++e) {
             unsigned packed_k = 0;
             {
+                // (a value outside [0, 1] clamps to a key whose float it is not: no separate range check; arithmetic, no table)
                 const float v = x[e];
-                const float kf = rintf(v * 1000.0f);
-                const bool inr = kf >= 0.0f && kf <= 1000.0f;        // false for NaN
-                const int k = inr ? (int)kf : 0;
-                ok = ok && (v != v || (inr && ps_of_key(kf) == v));          // (arithmetic, not T[k]: one LDS look-up fewer)
+                const float kf = __builtin_amdgcn_fmed3f(rintf(v * 1000.0f), 0.0f, 1000.0f);
+                const int k = (int)kf;
+                ok = ok && (v != v || ps_of_key(kf) == v);
                 packed_k = (v != v) ? 0u : (unsigned)(k + 1);
             }
             {
                 const float v = y[e];
-                const float kf = rintf(v * 1000.0f);
-                const bool inr = kf >= 0.0f && kf <= 1000.0f;
-                const int k = inr ? (int)kf : 0;
-                ok = ok && (v != v || (inr && ps_of_key(kf) == v));
+                const float kf = __builtin_amdgcn_fmed3f(rintf(v * 1000.0f), 0.0f, 1000.0f);
+                const int k = (int)kf;
+                ok = ok && (v != v || ps_of_key(kf) == v);
                 packed_k |= (v != v) ? 0u : ((unsigned)(k + 1) << 16);
             }
             kk[e] = packed_k;
