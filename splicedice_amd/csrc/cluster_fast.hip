@@ -76,6 +76,8 @@ struct FastArgs {
     uint32_t* bmax64;      // [ceil(n/64)] max right per 64 rows
     unsigned long long* tile_state;   // look-back granules of the neighbour kernel
     int32_t* row_of; int64_t* row_ptr; int32_t* col; int64_t col_cap;
+    uint32_t* blkneed;     // [ceil(n/16)] per block of 16 rows: rows its lists reach below the block's first row | beyond its
+                           // last row << 8 (each saturating at 255): the PS kernel sizes a tile's halo from it
     int spb;               // sample keys per bucket
     int sample_sort;       // buckets of 512..4096 keys: LDS-local sample sort (param cluster.sample_sort, default 1)
     int ablate;            // timing experiments only (param cluster.ablate): results are wrong when set
@@ -730,7 +732,7 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     const int nr = min(T, n - t0);
     if (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW | ST_DUP)) {
         // failed chain: leave an all-zero row_ptr (every list empty) so that a dependent launch stays in bounds
-        if (t < nr) a.row_ptr[t0 + t] = 0;
+        if (t < nr) { a.row_ptr[t0 + t] = 0; if ((t & 15) == 0) a.blkneed[(t0 + t) >> 4] = 0; }
         if (t0 + t == 0) a.row_ptr[n] = 0;
         return;
     }
@@ -884,6 +886,20 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
         if (deg > (uint32_t)KMAX) redo = true;
     }
     uint32_t reach = (uint32_t)max(r - far_b, far_f - r);
+    {
+        // per 16-row block (tiles start at multiples of 16): how far the lists reach beyond the block on either side
+        const int b16 = t & 15;
+        const unsigned lo_n = act ? (unsigned)min(max(r - far_b - b16, 0), 255) : 0u;
+        const unsigned hi_n = act ? (unsigned)min(max(far_f - r - (15 - b16), 0), 255) : 0u;
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        us2 pk = {(unsigned short)lo_n, (unsigned short)hi_n};
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const unsigned y = (unsigned)__shfl_xor((int)__builtin_bit_cast(unsigned, pk), o);
+            pk = __builtin_elementwise_max(pk, __builtin_bit_cast(us2, y));
+        }
+        if (act && b16 == 0) a.blkneed[r >> 4] = (uint32_t)pk.x | ((uint32_t)pk.y << 8);
+    }
     // ---- workgroup exclusive scan of the degrees, look-back for the global offset
     uint32_t x = deg;
 #pragma unroll
@@ -1007,6 +1023,7 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
 int launch_neighbours(sdice_ctx* ctx, FastPlan& pl) {
     pl.a.col = ctx->d_col;
     pl.a.col_cap = ctx->col_cap;
+    pl.a.blkneed = ctx->d_reach;
     SD_LAUNCH(ctx, "neighbours_kernel", (neighbours_kernel<NB_T>), dim3((unsigned)pl.n_tiles), dim3(NB_T), 0, pl.a);
     return SDICE_OK;
 }
@@ -1025,6 +1042,24 @@ int ensure_col(sdice_ctx* ctx, int64_t want) {
         return SDICE_ERR_NOMEM;
     }
     ctx->col_cap = want;
+    return SDICE_OK;
+}
+
+int ensure_reach(sdice_ctx* ctx, int64_t n) {       // one word per 16 rows
+    n = sd_ceil_div(n, 16) + 1;
+    if (n <= ctx->reach_cap) return SDICE_OK;
+    if (ctx->d_reach) {
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_reach);
+    }
+    ctx->d_reach = nullptr;
+    ctx->reach_cap = 0;
+    hipError_t e = hipMalloc((void**)&ctx->d_reach, (size_t)n * 4);
+    if (e != hipSuccess) {
+        sdice_set_error("sdice_cluster: hipMalloc of %lld block-reach entries failed: %s", (long long)n, hipGetErrorString(e));
+        return SDICE_ERR_NOMEM;
+    }
+    ctx->reach_cap = n;
     return SDICE_OK;
 }
 
@@ -1095,6 +1130,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
     SD_HIP(hipSetDevice(ctx->device));
     ctx->cluster_pending = false;
+    ctx->reach_n = 0;
     const bool legacy = n > FAST_MAX_N || ctx->param("cluster.generic", 0) || ctx->param("cluster.legacy", 0);
     if (legacy || n == 0) return sd_cluster_legacy(ctx, n, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, nnz_out);
     SD_ARG(d_chrom && d_left && d_right && d_strand && d_row_of && d_row_ptr, "NULL pointer");
@@ -1107,6 +1143,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     FastArgs& a = pl.a;
     // list capacity: what the last clustering needed, at least 16 entries per junction
     SD_TRY(ensure_col(ctx, 16 * n + 1024));
+    SD_TRY(ensure_reach(ctx, n));
 
     SD_HIP(hipMemsetAsync(pl.zero_base, 0, pl.zero_bytes, ctx->stream));
     if (a.S == 0) SD_HIP(hipMemsetAsync(a.sb, 0, (size_t)SB_WORDS * 8, ctx->stream));   // (else cleared by the rank kernel)
@@ -1137,6 +1174,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
 
     if (!nnz_out) {          // asynchronous: the status is resolved at the next synchronising call
         ctx->cluster_pending = true;
+        ctx->reach_n = n;    // (a failed chain leaves empty lists and zero reach)
         return SDICE_OK;
     }
     unsigned long long flags = 0;
@@ -1160,6 +1198,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     }
     ctx->nnz = nnz;
     ctx->cluster_reach = (int)reach;
+    ctx->reach_n = n;
     *nnz_out = nnz;
     return SDICE_OK;
 }

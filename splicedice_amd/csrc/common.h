@@ -70,6 +70,12 @@ struct sdice_ctx {
     int64_t col_cap = 0;
     int64_t nnz = 0;
     int cluster_reach = 0;   // max |row(neighbour) - row| of the last clustering (PS halo hint)
+    // reach of the lists in d_col per block of 16 rows (fast clustering path): low byte = rows the block's lists reach
+    // below its first row, next byte = rows beyond its last row, both saturating at 255; the PS kernel sizes a tile's
+    // halo from it
+    uint32_t* d_reach = nullptr;
+    int64_t reach_cap = 0;   // words
+    int64_t reach_n = 0;     // rows d_reach describes; 0 = not valid for d_col (generic clustering path, no clustering yet)
     int64_t* h_pinned = nullptr;  // small pinned buffer for scalar read-backs
     void* cluster_sb = nullptr;   // device status block of the fast clustering path (persistent, 768 B)
     bool cluster_pending = false; // an asynchronous sdice_cluster_dev has not been resolved yet

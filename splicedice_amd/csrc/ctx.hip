@@ -130,6 +130,7 @@ extern "C" int sdice_ctx_destroy(sdice_ctx* ctx) {
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->d_col) (void)hipFree(ctx->d_col);
+    if (ctx->d_reach) (void)hipFree(ctx->d_reach);
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
     if (ctx->cluster_sb) (void)hipFree(ctx->cluster_sb);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -321,7 +322,7 @@ extern "C" int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms) {
 extern "C" int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value) {
     SD_ARG(ctx && name, "bad arguments");
     static const char* known[] = {"ps.lds_bytes", "ps.tile_rows", "ps.threads", "ps.chunk_cols",
-                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "sort.rounds", "ranksum.variant", "ranksum.ablate",
+                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "ps.dma", "ps.use_reach", "sort.rounds", "ranksum.variant", "ranksum.ablate",
                                   "fisher.table_max", "fisher.refill", "fisher.unroll", "bh.columns_path", "bh.reg_cap", "bh.mean", "bh.spb", nullptr};
     for (int i = 0; known[i]; ++i)
         if (strcmp(known[i], name) == 0) {

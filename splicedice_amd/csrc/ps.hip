@@ -52,6 +52,9 @@ struct PsArgs {
     int n_chunks;       // column chunks per row tile
     int prio;           // raise the wave priority while the window loads go out (param ps.prio, default 1)
     int nt;             // non-temporal window loads (param ps.nt_loads, default 1; unchunked tables only)
+    // LDS-DMA kernel only:
+    const uint32_t* reach;  // reach words of the lists per block of 16 rows (below | beyond << 8, 255 = that far or further), NULL: stage `halo` rows
+    int lv_shift;       // log2(chunk_cols / 4) when that is a power of two, else -1
 };
 
 __device__ __forceinline__ int4 nt_load(const int4* p) {
@@ -215,7 +218,7 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
 template <int VEC, bool WEXCL, bool WPS, bool Q3, int ABL>
 __device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB, const int* colL, bool col_in_lds,
                                              int64_t kbase, int k0, int k1, int slo, int wrows, int ldw, int c0, int cvec,
-                                             int own_off, int64_t out_index) {
+                                             int own_off, int64_t out_index, int wbase) {
     typedef typename Vt<VEC>::I VI;
     unsigned long long acc[VEC];
 #pragma unroll
@@ -228,7 +231,7 @@ __device__ __forceinline__ void ps_item_slow(const PsArgs& a, const char* tileB,
         } else {
             const int j = a.nt ? __builtin_nontemporal_load(a.col + kbase + k) : a.col[kbase + k];
             const unsigned rel = (unsigned)(j - slo);
-            off = rel < (unsigned)wrows ? (int)(rel * (unsigned)ldw * 4u) : -1 - j;
+            off = rel < (unsigned)wrows ? (int)((unsigned)(j - wbase) * (unsigned)ldw * 4u) : -1 - j;
         }
         VI v;
         if (off >= 0) v = *reinterpret_cast<const VI*>(tileB + off + cbytes);
@@ -388,7 +391,7 @@ __device__ __forceinline__ void ps_tile_work(const PsArgs& a, const int bid, con
                               : ps_item_fast<VEC, WEXCL, WPS, true, Q3, ABL>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
             if (!done)
                 ps_item_slow<VEC, WEXCL, WPS, Q3, ABL>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
-                                              own_off, o);
+                                              own_off, o, slo);
             c += dc; ri += dr;
             if (c >= V) { c -= V; ri += 1; }
         }
@@ -403,6 +406,244 @@ template <int VEC, bool WEXCL, bool WPS, bool Q3, int ABL>
 __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
     extern __shared__ int4 smem4[];
     ps_tile_work<VEC, WEXCL, WPS, Q3, ABL>(a, blockIdx.x, threadIdx.x, smem4);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the tile kernel (VEC = 4 tables; the default).  Same tile / item scheme, but
+//   * the window goes global -> LDS by `global_load_lds_dwordx4` (1 KiB per wave instruction, no VGPRs, no
+//     ds_write pass, nothing for the VALU to do): a wave sends out its share of the tile's OWN rows first;
+//   * the halo is sized per tile from the reach that the clustering kernel leaves next to its lists, one word per
+//     block of 16 rows (neighbours_kernel, cluster_fast.hip; tiles are whole blocks): 16 rows in all on gene-shaped
+//     data instead of 2 x 16 fixed, and no neighbour misses the window (a list reaching further than the LDS holds,
+//     or a foreign CSR without reach words and a far neighbour, still takes the global-memory item path: any valid
+//     CSR is exact);
+//   * the tile's uniform scalars (first / last row pointer, four reach words) are SCALAR loads in one asm
+//     statement: they return on lgkmcnt, so waiting for them does not drain the DMA queue (hipcc waits vmcnt(0)
+//     for any vector load of its own while a DMA is in flight; asm vector loads with counted waits were tried --
+//     hipcc copies their destination registers ahead of the wait statement, i.e. before the data has landed);
+//   * the per-tile count bound is taken from LDS after the window has landed; flags go through per-wave LDS
+//     slots (no initialisation, no atomics).
+// LDS-DMA honours EXEC (tools/mb/dma_exec.hip: inactive lanes neither load nor store, active lanes keep their
+// lane slot), and its instruction offset moves the global AND the LDS address (tools/mb/psring.hip).
+// One all-zero row sits behind the window (short neighbour batches are padded with it).
+__device__ __forceinline__ void glds16(const void* gbase, unsigned voff, unsigned lds_dst, bool nt) {
+    // lane l: 16 B from gbase + voff (gbase and lds_dst wave-uniform, voff per lane) to LDS lds_dst + 16 l; M0 saved and restored
+    unsigned keep;
+    if (nt)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gbase, unsigned voff, unsigned lds_dst) {
+    // lane l: 4 B from gbase + voff to LDS lds_dst + 4 l
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+// Rows [row, row + rows) x this chunk's columns -> LDS rows of LV vectors from byte lds0, in pieces of 64 vectors (one
+// wave instruction each); piece q goes to wave (first_wave + q) % NW.  Whole rows (rpp == 0) are one contiguous run;
+// a column chunk has LV dividing 64, so a piece is rpp = 64 / LV row segments and every lane keeps its column.
+struct DmaGeom { const int32_t* counts; int s, c0, V, LV, rpp; bool nt; };
+__device__ __forceinline__ void dma_rows(const DmaGeom& d, int64_t row, int rows, unsigned lds0, int first_wave, int wave, int NW, int lane) {
+    int p = wave - first_wave;
+    if (p < 0) p += NW;
+    const char* gbase;
+    unsigned voff, vstep;
+    int plim;                                  // this lane takes part in pieces p < plim
+    int npieces;
+    if (d.rpp == 0) {
+        const int total = rows * d.LV;
+        gbase = reinterpret_cast<const char*>(d.counts + row * d.s);
+        voff = (unsigned)lane * 16u;
+        vstep = 1024u;
+        plim = (total - lane + 63) >> 6;
+        npieces = (total + 63) >> 6;
+    } else {
+        const int lr = lane / d.LV, cc = lane - lr * d.LV;
+        gbase = reinterpret_cast<const char*>(d.counts + row * d.s + d.c0);
+        voff = ((unsigned)lr * (unsigned)d.s + (unsigned)cc * 4u) * 4u;
+        vstep = (unsigned)d.rpp * (unsigned)d.s * 4u;
+        plim = cc < d.V ? (rows - lr + d.rpp - 1) / d.rpp : 0;
+        npieces = (rows + d.rpp - 1) / d.rpp;
+    }
+    voff += (unsigned)p * vstep;
+    unsigned dst = lds0 + (unsigned)p * 1024u;
+    for (; p < npieces; p += NW) {
+        if (p < plim) glds16(gbase, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)dst), d.nt);
+        voff += vstep * (unsigned)NW;
+        dst += 1024u * (unsigned)NW;
+    }
+}
+
+template <bool WEXCL, bool WPS, bool Q3>
+__global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      // 64 VGPRs: 32 waves per CU
+    extern __shared__ int4 smem4[];
+    constexpr int VEC = 4;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = T >> 6;
+    const int win_cap = a.tile_rows + 2 * a.halo;
+    int* tileL = reinterpret_cast<int*>(smem4);
+    int* colL = tileL + (size_t)(win_cap + 1) * a.chunk_cols;   // row win_cap is the all-zero padding row
+    int* rpS = colL + a.col_cap;                                 // the tile's row pointers as they stand in HBM (int64; the low words are used)
+    // per wave: [w] a staged neighbour lies outside the window, [16 + w] max count, [32 + w] max degree (no
+    // initialisation, no atomics: every wave writes its slots before the barrier that precedes their use)
+    unsigned* red = reinterpret_cast<unsigned*>(rpS + 2 * (a.tile_rows + 1));
+
+    const int bid = blockIdx.x;
+    int tile = bid / a.n_chunks;
+    int chunk = bid - tile * a.n_chunks;
+    if (a.tiles_per_xcd) {
+        const int k = bid >> 3;
+        const int t_local = k / a.n_chunks;
+        chunk = k - t_local * a.n_chunks;
+        tile = (bid & 7) * a.tiles_per_xcd + t_local;
+    }
+    if (tile >= a.n_tiles) return;
+    const int c0 = chunk * a.chunk_cols;
+    const int cwc = min(a.chunk_cols, a.s - c0);
+    const int V = cwc / VEC;
+    const int ldw = a.chunk_cols, LV = ldw / VEC;
+    const int64_t r0 = (int64_t)tile * a.tile_rows;
+    const int nr = (int)min((int64_t)a.tile_rows, a.n - r0);
+    const int wbase = (int)r0 - a.halo;                     // row that LDS window row 0 stands for (may be negative)
+    const unsigned lds_win = (unsigned)(uintptr_t)tileL;
+    const int rowb = ldw * 4;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    for (int i = tid; i < a.chunk_cols; i += T) tileL[(size_t)win_cap * a.chunk_cols + i] = 0;
+    const int zero_off = win_cap * a.chunk_cols * 4;
+
+    // ---- the tile's own rows go out first (they depend on nothing but the tile index)
+    DmaGeom d;
+    d.counts = a.counts; d.s = a.s; d.c0 = c0; d.V = V; d.LV = LV; d.nt = a.nt != 0;
+    d.rpp = (V == LV && cwc == a.s) ? 0 : 64 / LV;
+    dma_rows(d, r0, nr, lds_win + (unsigned)(a.halo * rowb), 0, wave, NW, lane);
+
+    // ---- uniform scalars of the tile: first / last row pointer, reach words of its two first and two last blocks
+    long long kbase, kend;
+    int nlo = a.halo, nhi = a.halo;
+    {
+        const int64_t* pf = a.row_ptr + r0;
+        const int64_t* pl = a.row_ptr + r0 + nr;
+        if (a.reach) {
+            const int b0 = (int)(r0 >> 4), bl = (int)((r0 + nr - 1) >> 4);
+            const uint32_t* q0 = a.reach + b0;
+            const uint32_t* q1 = a.reach + min(b0 + 1, bl);
+            const uint32_t* q2 = a.reach + max(bl - 1, b0);
+            const uint32_t* q3 = a.reach + bl;
+            unsigned w0, w1, w2, w3;
+            asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %6, 0x0\n\ts_load_dwordx2 %1, %7, 0x0\n\t"
+                         "s_load_dword %2, %8, 0x0\n\ts_load_dword %3, %9, 0x0\n\t"
+                         "s_load_dword %4, %10, 0x0\n\ts_load_dword %5, %11, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(kbase), "=&s"(kend), "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
+                         : "s"(pf), "s"(pl), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory");
+            // block b reaches (w & 255) rows below row 16 b and (w >> 8 & 255) rows beyond row 16 b + 15
+            const int e = (int)(r0 + nr - 1);
+            int lo_need = (int)(w0 & 255u);
+            if (b0 + 1 <= bl) lo_need = max(lo_need, (int)(w1 & 255u) - 16);
+            int hi_need = ((bl << 4) + 15 + (int)((w3 >> 8) & 255u)) - e;
+            if (bl - 1 >= b0) hi_need = max(hi_need, (((bl - 1) << 4) + 15 + (int)((w2 >> 8) & 255u)) - e);
+            nlo = min(max(lo_need, 0), a.halo);
+            nhi = min(max(hi_need, 0), a.halo);
+        } else {
+            asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(kbase), "=&s"(kend) : "s"(pf), "s"(pl) : "memory");
+        }
+    }
+    const int64_t nk = kend - kbase;
+
+    // ---- halo: what the lists of this tile reach beyond it (capped by the LDS window)
+    const int slo = (int)max((int64_t)0, r0 - nlo);
+    const int shi = (int)min(a.n, r0 + nr + nhi);
+    const int wrows = shi - slo;
+    {
+        const int ppr = d.rpp;
+        const int core_pieces = ppr ? (nr + ppr - 1) / ppr : (nr * LV + 63) >> 6;
+        const int lo_rows = (int)r0 - slo, hi_rows = shi - (int)(r0 + nr);
+        const int lo_pieces = ppr ? (lo_rows + ppr - 1) / ppr : (lo_rows * LV + 63) >> 6;
+        if (lo_rows > 0) dma_rows(d, slo, lo_rows, lds_win + (unsigned)((slo - wbase) * rowb), core_pieces % NW, wave, NW, lane);
+        if (hi_rows > 0) dma_rows(d, r0 + nr, hi_rows, lds_win + (unsigned)((a.halo + nr) * rowb), (core_pieces + lo_pieces) % NW, wave, NW, lane);
+    }
+    {
+        // the tile's nr + 1 row pointers, raw, 64 dwords per instruction
+        const int nd = 2 * (nr + 1);
+        const int first = (wave + NW - 3 % NW) % NW;        // (not the waves that took the first window pieces)
+        for (int q = first; q * 64 < nd; q += NW)
+            if (q * 64 + lane < nd)
+                glds4(a.row_ptr + r0, (unsigned)(q * 64 + lane) * 4u,
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)rpS + (unsigned)q * 256u)));
+    }
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
+
+    // ---- CSR segment -> LDS: relative row pointers, neighbour LDS offsets
+    const bool col_in_lds = nk <= (int64_t)a.col_cap;
+    {
+        bool outside = false;
+        if (col_in_lds) {
+            for (int k = tid; k < (int)nk; k += T) {
+                const int j = a.col[kbase + k];
+                const bool in = (unsigned)(j - slo) < (unsigned)wrows;
+                outside = outside || !in;
+                colL[k] = in ? (j - wbase) * rowb : -1 - j;
+            }
+        }
+        const unsigned long long any = __ballot(outside);
+        if (lane == 0) red[wave] = any != 0ull ? 1u : 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+    __syncthreads();
+    // ---- bounds of the tile: largest staged count (from LDS), largest degree
+    {
+        unsigned cmax = 0, dmax = 0;
+        const int4* win4 = reinterpret_cast<const int4*>(tileL) + (size_t)(slo - wbase) * LV;
+        const int total = wrows * LV;
+        if (V == LV) {
+            for (int i = tid; i < total; i += T) { const int4 v = win4[i]; cmax = max(cmax, vmax(v)); }
+        } else {
+            for (int i = tid; i < total; i += T) {
+                const int rr = a.lv_shift >= 0 ? i >> a.lv_shift : i / LV;
+                if (i - rr * LV < V) { const int4 v = win4[i]; cmax = max(cmax, vmax(v)); }
+            }
+        }
+        for (int i = tid; i < nr; i += T) dmax = max(dmax, (unsigned)(rpS[2 * i + 2] - rpS[2 * i]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o));
+            dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o));
+        }
+        if (lane == 0) { red[16 + wave] = cmax; red[32 + wave] = dmax; }
+    }
+    __syncthreads();
+    unsigned tile_cmax = 0, tile_dmax = 0, tile_out = 0;
+    for (int w = 0; w < NW; ++w) { tile_out |= red[w]; tile_cmax = max(tile_cmax, red[16 + w]); tile_dmax = max(tile_dmax, red[32 + w]); }
+    const unsigned thr = 0xFFFFFFu / (tile_dmax + 1u);   // per-count bound keeping incl+excl < 2^24
+    const bool fast = tile_cmax <= thr && col_in_lds;     // block-uniform
+    const bool all_in = tile_out == 0u;                   // block-uniform: no per-batch window check needed
+
+    // ---- per (row, vector) item: gather neighbours from LDS, divide, store
+    {
+        const char* tileB = reinterpret_cast<const char*>(tileL);
+        const int items = nr * V;
+        int ri = tid / V, c = tid - ri * V;
+        const int dr = T / V, dc = T - dr * V;
+        const int kb = (int)kbase;
+        for (int it = tid; it < items; it += T) {
+            const int k0 = rpS[2 * ri] - kb, k1 = rpS[2 * ri + 2] - kb;   // (differences of the low words: lists are < 2^31 entries)
+            const int64_t o = (r0 + ri) * a.s + c0 + c * VEC;
+            const int own_off = (a.halo + ri) * rowb;
+            bool done = false;
+            if (fast)
+                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
+                              : ps_item_fast<VEC, WEXCL, WPS, true, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
+            if (!done)
+                ps_item_slow<VEC, WEXCL, WPS, Q3, 0>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
+                                                     own_off, o, wbase);
+            c += dc; ri += dr;
+            if (c >= V) { c -= V; ri += 1; }
+        }
+    }
 }
 
 __global__ void quantize3_kernel(float* __restrict__ x, int64_t n) {
@@ -441,6 +682,21 @@ int launch_ps_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3
     return SDICE_OK;
 }
 
+template <bool WE, bool WP, bool Q3>
+int launch_ps_dma_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_dma_kernel<WE, WP, Q3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_dma_kernel<WE, WP, Q3>), grid, dim3(threads), lds, a);
+    return SDICE_OK;
+}
+int launch_ps_dma(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps, bool q3) {
+    if (wexcl && wps) return q3 ? launch_ps_dma_one<true, true, true>(ctx, a, threads, lds, grid)
+                                : launch_ps_dma_one<true, true, false>(ctx, a, threads, lds, grid);
+    if (wexcl) return launch_ps_dma_one<true, false, false>(ctx, a, threads, lds, grid);
+    return q3 ? launch_ps_dma_one<false, true, true>(ctx, a, threads, lds, grid)
+              : launch_ps_dma_one<false, true, false>(ctx, a, threads, lds, grid);
+}
+
 template <int VEC>
 int launch_ps(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps, bool q3, int abl) {
     if (abl && VEC == 4 && !wexcl && wps && !q3) {        // timing experiments (one shape only)
@@ -477,10 +733,14 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     const bool aligned = ((uintptr_t)d_counts % 16 == 0) && (!d_ps || (uintptr_t)d_ps % 16 == 0) &&
                          (!d_excl || (uintptr_t)d_excl % 16 == 0);
     const int vec = (s % 4 == 0 && aligned) ? 4 : 1;
-    int64_t lds = ctx->param("ps.lds_bytes", 80 * 1024);   // two workgroups per CU (160 KiB LDS)
+    const int abl = (int)ctx->param("ps.ablate", 0);
+    // window by LDS-DMA + halo from the clustering's reach bytes (ps_tile_dma_kernel); the register-staged kernel
+    // serves tables whose rows are not 16-byte vectors and the timing experiments
+    const bool dma = vec == 4 && abl == 0 && ctx->param("ps.dma", 1) != 0;
+    int64_t lds = ctx->param("ps.lds_bytes", dma ? 40 * 1024 : 80 * 1024);   // four (two) workgroups per CU (160 KiB LDS)
     if (lds > 160 * 1024) lds = 160 * 1024;
     if (lds < 8 * 1024) lds = 8 * 1024;
-    int threads = (int)ctx->param("ps.threads", 1024);
+    int threads = (int)ctx->param("ps.threads", dma ? 512 : 1024);
     threads = (threads / 64) * 64;
     if (threads < 64) threads = 64;
     if (threads > 1024) threads = 1024;
@@ -495,32 +755,40 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
 
     // LDS budget (ints): (R + 2H) * cw window + 16 R staged neighbour offsets + (R + 1) row
     // pointers + 8 scratch
-    const int64_t L = lds / 4 - 16;
+    const int64_t L = lds / 4 - (dma ? 64 : 16);      // (the LDS-DMA kernel keeps 48 per-wave flag words behind the row pointers)
+    const bool have_reach = dma && d_col != nullptr && d_col == ctx->d_col && ctx->reach_n == n && ctx->d_reach != nullptr &&
+                            ctx->param("ps.use_reach", 1) != 0;
     int64_t H = ctx->param("ps.halo_rows", -1);
     if (H < 0) {
-        // rows further than the halo are still summed exactly (global-memory path); 16 rows cover
-        // >99.9 % of the neighbours of gene-shaped data, less if the clustering saw a smaller reach
+        // rows further than the halo are still summed exactly (global-memory path).  With reach bytes H is the
+        // CAPACITY of the window on each side (a tile stages what its lists reach, 8 + 8 rows on average on
+        // gene-shaped data, 22 at most); without them H rows are staged on each side: 16 cover >99.9 % of the
+        // neighbours of gene-shaped data, less if the clustering saw a smaller reach
         H = 16;
-        if (d_col != nullptr && d_col == ctx->d_col && ctx->cluster_reach > 0 && ctx->cluster_reach < H)
+        if (!have_reach && d_col != nullptr && d_col == ctx->d_col && ctx->cluster_reach > 0 && ctx->cluster_reach < H)
             H = ctx->cluster_reach;
     }
     // (a software-pipelined persistent variant -- one workgroup per CU, two LDS buffers, next tile's
     //  loads in flight during the gather -- was built and measured 30 % slower: the kernel is VALU-issue
     //  bound, and halving the resident waves costs more than hiding the load latency gains)
+    const int64_t r_max = 2 * threads;   // (the register-staged kernel keeps two row pointers per thread in registers)
+    const int64_t per_row = dma ? 18 : 17;  // 16 staged neighbour offsets + the row pointer (raw int64 in the LDS-DMA kernel)
     int64_t R = ctx->param("ps.tile_rows", 0);
-    if (R <= 0) R = (L - (2 * H + 1) * cw) / (cw + 17);
-    if (R > 2 * threads) R = 2 * threads;   // the kernel keeps two row pointers per thread in registers
-    while (H > 0 && (R < 8 || (R + 2 * H + 1) * cw + 17 * R > L)) {
+    if (R <= 0) R = (L - (2 * H + 1) * cw) / (cw + per_row);
+    if (R > r_max) R = r_max;
+    while (H > 0 && (R < 8 || (R + 2 * H + 1) * cw + per_row * R > L)) {
         // window does not fit: shrink the halo first (misses fall back to global loads), then the tile
         H = H / 2;
-        if (ctx->param("ps.tile_rows", 0) <= 0) R = (L - (2 * H + 1) * cw) / (cw + 17);
-        if (R > 2 * threads) R = 2 * threads;
+        if (ctx->param("ps.tile_rows", 0) <= 0) R = (L - (2 * H + 1) * cw) / (cw + per_row);
+        if (R > r_max) R = r_max;
     }
     if (R < 1) R = 1;
-    while (R > 1 && (R + 2 * H + 1) * cw + 17 * R > L) R -= 1;
-    SD_ARG((R + 2 * H + 1) * cw + 17 * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
+    while (R > 1 && (R + 2 * H + 1) * cw + per_row * R > L) R -= 1;
+    SD_ARG((R + 2 * H + 1) * cw + per_row * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
     // (trimming R so that R * V is a multiple of the block size was measured: slower -- the per-tile
     //  fixed cost outweighs the idle lanes of the last pass over the items)
+    if (have_reach && R >= 16 && ctx->param("ps.tile_rows", 0) <= 0) R &= ~(int64_t)15;   // tiles are whole 16-row reach blocks
+    const bool use_reach = have_reach && R % 16 == 0;
     if (R > n) { R = n; }
 
     PsArgs a;
@@ -537,9 +805,11 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     // window loads that do not linger in the L2: -4 % at 1 M x 100 (0.179 -> 0.172 ms in one process); with column chunks
     // the lines shared by two chunks and the halo rows want the L2 (+1.7 % at 2 M x 500): unchunked tables only
     a.nt = ctx->param("ps.nt_loads", 1) != 0 && n_chunks == 1;
+    a.reach = use_reach ? ctx->d_reach : nullptr;
+    a.lv_shift = -1;
+    for (int b = 0; b < 16; ++b) if ((cw / 4) == (1 << b)) a.lv_shift = b;
     int gx = a.n_tiles;
     a.tiles_per_xcd = 0;
-    const int abl = (int)ctx->param("ps.ablate", 0);
     const bool q3 = ctx->param("ps.quantize3", 0) != 0;
     if (ctx->param("ps.xcd_remap", 1) && a.n_tiles >= 64) {
         a.tiles_per_xcd = (int)sd_ceil_div(a.n_tiles, 8);
@@ -548,6 +818,7 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     const size_t lds_bytes = (size_t)lds;
     SD_ARG((int64_t)gx * n_chunks < (int64_t)1 << 31, "grid too large");
     dim3 grid((unsigned)((int64_t)gx * n_chunks));
+    if (dma) return launch_ps_dma(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3);
     if (vec == 4) return launch_ps<4>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
     return launch_ps<1>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
 }
