@@ -54,7 +54,8 @@ struct PsArgs {
     int nt;             // non-temporal window loads (param ps.nt_loads, default 1; unchunked tables only)
     // LDS-DMA kernel only:
     const uint32_t* reach;  // reach words of the lists per block of 16 rows (below | beyond << 8, 255 = that far or further), NULL: stage `halo` rows
-    int lv_shift;       // log2(chunk_cols / 4) when that is a power of two, else -1
+    int lv_shift;       // column chunks: log2(row segments of a chunk per 1 KiB piece) (chunk_cols / 4 divides 64)
+    int dbg;            // timing experiments on the LDS-DMA kernel (param ps.dma_ablate; results are wrong when set)
 };
 
 __device__ __forceinline__ int4 nt_load(const int4* p) {
@@ -427,10 +428,10 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
 // LDS-DMA honours EXEC (tools/mb/dma_exec.hip: inactive lanes neither load nor store, active lanes keep their
 // lane slot), and its instruction offset moves the global AND the LDS address (tools/mb/psring.hip).
 // One all-zero row sits behind the window (short neighbour batches are padded with it).
-__device__ __forceinline__ void glds16(const void* gbase, unsigned voff, unsigned lds_dst, bool nt) {
+template <bool NT> __device__ __forceinline__ void glds16(const void* gbase, unsigned voff, unsigned lds_dst) {
     // lane l: 16 B from gbase + voff (gbase and lds_dst wave-uniform, voff per lane) to LDS lds_dst + 16 l; M0 saved and restored
     unsigned keep;
-    if (nt)
+    if (NT)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
     else
@@ -443,42 +444,73 @@ __device__ __forceinline__ void glds4(const void* gbase, unsigned voff, unsigned
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
-// Rows [row, row + rows) x this chunk's columns -> LDS rows of LV vectors from byte lds0, in pieces of 64 vectors (one
-// wave instruction each); piece q goes to wave (first_wave + q) % NW.  Whole rows (rpp == 0) are one contiguous run;
-// a column chunk has LV dividing 64, so a piece is rpp = 64 / LV row segments and every lane keeps its column.
-struct DmaGeom { const int32_t* counts; int s, c0, V, LV, rpp; bool nt; };
-__device__ __forceinline__ void dma_rows(const DmaGeom& d, int64_t row, int rows, unsigned lds0, int first_wave, int wave, int NW, int lane) {
-    int p = wave - first_wave;
-    if (p < 0) p += NW;
-    const char* gbase;
-    unsigned voff, vstep;
-    int plim;                                  // this lane takes part in pieces p < plim
-    int npieces;
-    if (d.rpp == 0) {
-        const int total = rows * d.LV;
-        gbase = reinterpret_cast<const char*>(d.counts + row * d.s);
-        voff = (unsigned)lane * 16u;
-        vstep = 1024u;
-        plim = (total - lane + 63) >> 6;
-        npieces = (total + 63) >> 6;
-    } else {
-        const int lr = lane / d.LV, cc = lane - lr * d.LV;
-        gbase = reinterpret_cast<const char*>(d.counts + row * d.s + d.c0);
-        voff = ((unsigned)lr * (unsigned)d.s + (unsigned)cc * 4u) * 4u;
-        vstep = (unsigned)d.rpp * (unsigned)d.s * 4u;
-        plim = cc < d.V ? (rows - lr + d.rpp - 1) / d.rpp : 0;
-        npieces = (rows + d.rpp - 1) / d.rpp;
-    }
-    voff += (unsigned)p * vstep;
-    unsigned dst = lds0 + (unsigned)p * 1024u;
-    for (; p < npieces; p += NW) {
-        if (p < plim) glds16(gbase, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)dst), d.nt);
-        voff += vstep * (unsigned)NW;
-        dst += 1024u * (unsigned)NW;
+// `bytes` contiguous bytes from gbase -> LDS from lds0, 1 KiB pieces; piece q goes to the wave with wave_rel == q mod NW
+template <bool NT>
+__device__ __forceinline__ void dma_run(const char* gbase, int bytes, unsigned lds0, int wave_rel, int NW, unsigned lane16) {
+    for (int off = wave_rel << 10; off < bytes; off += NW << 10)
+        if ((int)(off + lane16) < bytes) glds16<NT>(gbase, (unsigned)off + lane16, lds0 + (unsigned)off);
+}
+// `rows` row segments of one column chunk (LDS rows of 64 >> rsh vectors, V of them valid; 1 << rsh segments per piece)
+template <bool NT>
+__device__ __forceinline__ void dma_chunk_rows(const char* gbase, int rows, unsigned lds0, int wave_rel, int NW, int lane, int rsh,
+                                               int V, unsigned row_stride_bytes) {
+    const int lv = 64 >> rsh;
+    const int lr = lane >> (6 - rsh), cc = lane & (lv - 1);
+    const int npieces = (rows + (1 << rsh) - 1) >> rsh;
+    unsigned voff = ((unsigned)(wave_rel << rsh) + (unsigned)lr) * row_stride_bytes + (unsigned)cc * 16u;
+    const unsigned vstep = ((unsigned)NW << rsh) * row_stride_bytes;
+    for (int p = wave_rel; p < npieces; p += NW) {
+        if (cc < V && (p << rsh) + lr < rows) glds16<NT>(gbase, voff, lds0 + ((unsigned)p << 10));
+        voff += vstep;
     }
 }
 
-template <bool WEXCL, bool WPS, bool Q3>
+// maximum over the 64 lanes by DPP steps (VALU latency; six ds_bpermute round trips on the tile's critical path were
+// measurable): the result is valid in lane 63
+__device__ __forceinline__ unsigned wave_max_dpp(unsigned x) {
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));   // row_mirror
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true));   // row_bcast:15 -> rows 1, 3
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true));   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// largest count in the pieces that dma_run / dma_chunk_rows with the same arguments fetched for THIS wave (after its own
+// s_waitcnt vmcnt(0) they are visible to it: no barrier needed)
+__device__ __forceinline__ unsigned max_run(const char* ldsB, int bytes, int lds0, int wave_rel, int NW, unsigned lane16, unsigned m) {
+    // four reads in flight per trip (one LDS round trip instead of four on the tile's critical path)
+    const int step = NW << 10;
+    for (int off = (wave_rel << 10) + (int)lane16; off < bytes; off += 4 * step) {
+        const bool b1 = off + step < bytes, b2 = off + 2 * step < bytes, b3 = off + 3 * step < bytes;
+        const int4 z = make_int4(0, 0, 0, 0);
+        const int4 v0 = *reinterpret_cast<const int4*>(ldsB + lds0 + off);
+        const int4 v1 = b1 ? *reinterpret_cast<const int4*>(ldsB + lds0 + off + step) : z;
+        const int4 v2 = b2 ? *reinterpret_cast<const int4*>(ldsB + lds0 + off + 2 * step) : z;
+        const int4 v3 = b3 ? *reinterpret_cast<const int4*>(ldsB + lds0 + off + 3 * step) : z;
+        m = max(max(m, vmax(v0)), max(vmax(v1), max(vmax(v2), vmax(v3))));
+    }
+    return m;
+}
+__device__ __forceinline__ unsigned max_chunk_rows(const char* ldsB, int rows, int lds0, int wave_rel, int NW, int lane, int rsh, int V, unsigned m) {
+    const int lv = 64 >> rsh;
+    const int lr = lane >> (6 - rsh), cc = lane & (lv - 1);
+    if (cc >= V) return m;
+    const int lim = rows - lr;                              // piece p holds a row of this lane iff (p << rsh) < lim
+    const char* base = ldsB + lds0 + lane * 16;
+    for (int p = wave_rel; (p << rsh) < lim; p += 4 * NW) {
+        const bool b1 = ((p + NW) << rsh) < lim, b2 = ((p + 2 * NW) << rsh) < lim, b3 = ((p + 3 * NW) << rsh) < lim;
+        const int4 z = make_int4(0, 0, 0, 0);
+        const int4 v0 = *reinterpret_cast<const int4*>(base + (p << 10));
+        const int4 v1 = b1 ? *reinterpret_cast<const int4*>(base + ((p + NW) << 10)) : z;
+        const int4 v2 = b2 ? *reinterpret_cast<const int4*>(base + ((p + 2 * NW) << 10)) : z;
+        const int4 v3 = b3 ? *reinterpret_cast<const int4*>(base + ((p + 3 * NW) << 10)) : z;
+        m = max(max(m, vmax(v0)), max(vmax(v1), max(vmax(v2), vmax(v3))));
+    }
+    return m;
+}
+
+template <bool CHUNKED, bool WEXCL, bool WPS, bool Q3>
 __global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      // 64 VGPRs: 32 waves per CU
     extern __shared__ int4 smem4[];
     constexpr int VEC = 4;
@@ -486,49 +518,58 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      /
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = T >> 6;
     const int win_cap = a.tile_rows + 2 * a.halo;
     int* tileL = reinterpret_cast<int*>(smem4);
-    int* colL = tileL + (size_t)(win_cap + 1) * a.chunk_cols;   // row win_cap is the all-zero padding row
+    int* colL = tileL + (win_cap + 1) * a.chunk_cols;            // row win_cap is the all-zero padding row
     int* rpS = colL + a.col_cap;                                 // the tile's row pointers as they stand in HBM (int64; the low words are used)
-    // per wave: [w] a staged neighbour lies outside the window, [16 + w] max count, [32 + w] max degree (no
-    // initialisation, no atomics: every wave writes its slots before the barrier that precedes their use)
-    unsigned* red = reinterpret_cast<unsigned*>(rpS + 2 * (a.tile_rows + 1));
+    unsigned* red = reinterpret_cast<unsigned*>(rpS + ((2 * (a.tile_rows + 1) + 3) & ~3));   // one word per wave (16-byte aligned), see below
 
     const int bid = blockIdx.x;
-    int tile = bid / a.n_chunks;
-    int chunk = bid - tile * a.n_chunks;
-    if (a.tiles_per_xcd) {
-        const int k = bid >> 3;
-        const int t_local = k / a.n_chunks;
-        chunk = k - t_local * a.n_chunks;
-        tile = (bid & 7) * a.tiles_per_xcd + t_local;
+    int tile, chunk = 0;
+    if (!CHUNKED) {
+        tile = a.tiles_per_xcd ? (bid & 7) * a.tiles_per_xcd + (bid >> 3) : bid;
+    } else {
+        tile = bid / a.n_chunks;
+        chunk = bid - tile * a.n_chunks;
+        if (a.tiles_per_xcd) {
+            const int k = bid >> 3;
+            const int t_local = k / a.n_chunks;
+            chunk = k - t_local * a.n_chunks;
+            tile = (bid & 7) * a.tiles_per_xcd + t_local;
+        }
     }
     if (tile >= a.n_tiles) return;
     const int c0 = chunk * a.chunk_cols;
-    const int cwc = min(a.chunk_cols, a.s - c0);
+    const int cwc = CHUNKED ? min(a.chunk_cols, a.s - c0) : a.s;
     const int V = cwc / VEC;
     const int ldw = a.chunk_cols, LV = ldw / VEC;
-    const int64_t r0 = (int64_t)tile * a.tile_rows;
-    const int nr = (int)min((int64_t)a.tile_rows, a.n - r0);
-    const int wbase = (int)r0 - a.halo;                     // row that LDS window row 0 stands for (may be negative)
+    const int r0 = tile * a.tile_rows;                     // (n < 2^31)
+    const int nr = min(a.tile_rows, (int)a.n - r0);
+    const int wbase = r0 - a.halo;                         // row that LDS window row 0 stands for (may be negative)
     const unsigned lds_win = (unsigned)(uintptr_t)tileL;
     const int rowb = ldw * 4;
+    const unsigned lane16 = (unsigned)lane * 16u;
     if (a.prio) __builtin_amdgcn_s_setprio(3);
-    for (int i = tid; i < a.chunk_cols; i += T) tileL[(size_t)win_cap * a.chunk_cols + i] = 0;
+    for (int i = tid; i < LV; i += T) reinterpret_cast<int4*>(tileL + win_cap * a.chunk_cols)[i] = make_int4(0, 0, 0, 0);
     const int zero_off = win_cap * a.chunk_cols * 4;
 
     // ---- the tile's own rows go out first (they depend on nothing but the tile index)
-    DmaGeom d;
-    d.counts = a.counts; d.s = a.s; d.c0 = c0; d.V = V; d.LV = LV; d.nt = a.nt != 0;
-    d.rpp = (V == LV && cwc == a.s) ? 0 : 64 / LV;
-    dma_rows(d, r0, nr, lds_win + (unsigned)(a.halo * rowb), 0, wave, NW, lane);
+    const char* gtile = reinterpret_cast<const char*>(a.counts + (int64_t)r0 * a.s + c0);
+    const unsigned row_stride = (unsigned)a.s * 4u;
+    if (!CHUNKED) {
+        if (a.nt) dma_run<true>(gtile, nr * rowb, lds_win + (unsigned)(a.halo * rowb), wave, NW, lane16);
+        else      dma_run<false>(gtile, nr * rowb, lds_win + (unsigned)(a.halo * rowb), wave, NW, lane16);
+    } else {
+        dma_chunk_rows<false>(gtile, nr, lds_win + (unsigned)(a.halo * rowb), wave, NW, lane, a.lv_shift, V, row_stride);
+    }
 
     // ---- uniform scalars of the tile: first / last row pointer, reach words of its two first and two last blocks
     long long kbase, kend;
     int nlo = a.halo, nhi = a.halo;
     {
         const int64_t* pf = a.row_ptr + r0;
-        const int64_t* pl = a.row_ptr + r0 + nr;
-        if (a.reach) {
-            const int b0 = (int)(r0 >> 4), bl = (int)((r0 + nr - 1) >> 4);
+        const int64_t* pl = pf + nr;
+        if (a.dbg & 4) { kbase = 0; kend = 0; nlo = nhi = a.halo >> 1; }
+        else if (a.reach) {
+            const int b0 = r0 >> 4, bl = (r0 + nr - 1) >> 4;
             const uint32_t* q0 = a.reach + b0;
             const uint32_t* q1 = a.reach + min(b0 + 1, bl);
             const uint32_t* q2 = a.reach + max(bl - 1, b0);
@@ -540,11 +581,11 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      /
                          : "=&s"(kbase), "=&s"(kend), "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
                          : "s"(pf), "s"(pl), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory");
             // block b reaches (w & 255) rows below row 16 b and (w >> 8 & 255) rows beyond row 16 b + 15
-            const int e = (int)(r0 + nr - 1);
+            const int e = r0 + nr - 1;
             int lo_need = (int)(w0 & 255u);
-            if (b0 + 1 <= bl) lo_need = max(lo_need, (int)(w1 & 255u) - 16);
+            if (b0 < bl) lo_need = max(lo_need, (int)(w1 & 255u) - 16);
             int hi_need = ((bl << 4) + 15 + (int)((w3 >> 8) & 255u)) - e;
-            if (bl - 1 >= b0) hi_need = max(hi_need, (((bl - 1) << 4) + 15 + (int)((w2 >> 8) & 255u)) - e);
+            if (b0 < bl) hi_need = max(hi_need, (bl << 4) - 1 + (int)((w2 >> 8) & 255u) - e);
             nlo = min(max(lo_need, 0), a.halo);
             nhi = min(max(hi_need, 0), a.halo);
         } else {
@@ -552,75 +593,92 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      /
                          : "=&s"(kbase), "=&s"(kend) : "s"(pf), "s"(pl) : "memory");
         }
     }
-    const int64_t nk = kend - kbase;
+    const int nk = (int)(kend - kbase);
 
-    // ---- halo: what the lists of this tile reach beyond it (capped by the LDS window)
-    const int slo = (int)max((int64_t)0, r0 - nlo);
-    const int shi = (int)min(a.n, r0 + nr + nhi);
+    // ---- halo rows (what the lists of this tile reach beyond it, capped by the LDS window) and the row pointers
+    const int slo = max(0, r0 - nlo);
+    const int shi = min((int)a.n, r0 + nr + nhi);
     const int wrows = shi - slo;
     {
-        const int ppr = d.rpp;
-        const int core_pieces = ppr ? (nr + ppr - 1) / ppr : (nr * LV + 63) >> 6;
-        const int lo_rows = (int)r0 - slo, hi_rows = shi - (int)(r0 + nr);
-        const int lo_pieces = ppr ? (lo_rows + ppr - 1) / ppr : (lo_rows * LV + 63) >> 6;
-        if (lo_rows > 0) dma_rows(d, slo, lo_rows, lds_win + (unsigned)((slo - wbase) * rowb), core_pieces % NW, wave, NW, lane);
-        if (hi_rows > 0) dma_rows(d, r0 + nr, hi_rows, lds_win + (unsigned)((a.halo + nr) * rowb), (core_pieces + lo_pieces) % NW, wave, NW, lane);
-    }
-    {
+        const int lo_rows = r0 - slo, hi_rows = shi - (r0 + nr);
+        int w_lo = wave - (NW >> 1);      if (w_lo < 0) w_lo += NW;       // (not the waves that took the first window pieces)
+        int w_hi = wave - (NW >> 1) - 1;  if (w_hi < 0) w_hi += NW;
+        const char* glo = gtile - (int64_t)lo_rows * row_stride;
+        const char* ghi = gtile + (int64_t)nr * row_stride;
+        if (!CHUNKED) {
+            if (a.nt) {
+                dma_run<true>(glo, lo_rows * rowb, lds_win + (unsigned)((slo - wbase) * rowb), w_lo, NW, lane16);
+                dma_run<true>(ghi, hi_rows * rowb, lds_win + (unsigned)((a.halo + nr) * rowb), w_hi, NW, lane16);
+            } else {
+                dma_run<false>(glo, lo_rows * rowb, lds_win + (unsigned)((slo - wbase) * rowb), w_lo, NW, lane16);
+                dma_run<false>(ghi, hi_rows * rowb, lds_win + (unsigned)((a.halo + nr) * rowb), w_hi, NW, lane16);
+            }
+        } else {
+            dma_chunk_rows<false>(glo, lo_rows, lds_win + (unsigned)((slo - wbase) * rowb), w_lo, NW, lane, a.lv_shift, V, row_stride);
+            dma_chunk_rows<false>(ghi, hi_rows, lds_win + (unsigned)((a.halo + nr) * rowb), w_hi, NW, lane, a.lv_shift, V, row_stride);
+        }
         // the tile's nr + 1 row pointers, raw, 64 dwords per instruction
+        int w_rp = wave - 3;  while (w_rp < 0) w_rp += NW;
         const int nd = 2 * (nr + 1);
-        const int first = (wave + NW - 3 % NW) % NW;        // (not the waves that took the first window pieces)
-        for (int q = first; q * 64 < nd; q += NW)
-            if (q * 64 + lane < nd)
-                glds4(a.row_ptr + r0, (unsigned)(q * 64 + lane) * 4u,
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)rpS + (unsigned)q * 256u)));
+        for (int q = w_rp; q * 64 < nd; q += NW)
+            if (q * 64 + lane < nd) glds4(a.row_ptr + r0, (unsigned)(q * 64 + lane) * 4u, (unsigned)(uintptr_t)rpS + (unsigned)q * 256u);
     }
     if (a.prio) __builtin_amdgcn_s_setprio(0);
 
-    // ---- CSR segment -> LDS: relative row pointers, neighbour LDS offsets
-    const bool col_in_lds = nk <= (int64_t)a.col_cap;
-    {
-        bool outside = false;
-        if (col_in_lds) {
-            for (int k = tid; k < (int)nk; k += T) {
-                const int j = a.col[kbase + k];
-                const bool in = (unsigned)(j - slo) < (unsigned)wrows;
-                outside = outside || !in;
-                colL[k] = in ? (j - wbase) * rowb : -1 - j;
-            }
+    // ---- neighbour indices -> LDS byte offsets of their rows (or -1 - index for a row outside the window)
+    const bool col_in_lds = nk <= a.col_cap;
+    bool outside = false;
+    if (col_in_lds && !(a.dbg & 2)) {
+        for (int k = tid; k < nk; k += T) {
+            const int j = a.col[kbase + k];
+            const bool in = (unsigned)(j - slo) < (unsigned)wrows;
+            outside = outside || !in;
+            colL[k] = in ? (j - wbase) * rowb : -1 - j;
         }
-        const unsigned long long any = __ballot(outside);
-        if (lane == 0) red[wave] = any != 0ull ? 1u : 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
-    __syncthreads();
-    // ---- bounds of the tile: largest staged count (from LDS), largest degree
+    // ---- bound of the tile: the largest staged count, every wave over the pieces it fetched itself (no second barrier,
+    // no second pass: a pass of all threads over the window between two barriers cost 13 % of the kernel)
     {
-        unsigned cmax = 0, dmax = 0;
-        const int4* win4 = reinterpret_cast<const int4*>(tileL) + (size_t)(slo - wbase) * LV;
-        const int total = wrows * LV;
-        if (V == LV) {
-            for (int i = tid; i < total; i += T) { const int4 v = win4[i]; cmax = max(cmax, vmax(v)); }
-        } else {
-            for (int i = tid; i < total; i += T) {
-                const int rr = a.lv_shift >= 0 ? i >> a.lv_shift : i / LV;
-                if (i - rr * LV < V) { const int4 v = win4[i]; cmax = max(cmax, vmax(v)); }
+        unsigned cmax = 0;
+        if (!(a.dbg & 1)) {
+            const char* ldsB = reinterpret_cast<const char*>(tileL);
+            const int lo_rows = r0 - slo, hi_rows = shi - (r0 + nr);
+            int w_lo = wave - (NW >> 1);      if (w_lo < 0) w_lo += NW;
+            int w_hi = wave - (NW >> 1) - 1;  if (w_hi < 0) w_hi += NW;
+            if (!CHUNKED) {
+                cmax = max_run(ldsB, nr * rowb, a.halo * rowb, wave, NW, lane16, cmax);
+                cmax = max_run(ldsB, lo_rows * rowb, (slo - wbase) * rowb, w_lo, NW, lane16, cmax);
+                cmax = max_run(ldsB, hi_rows * rowb, (a.halo + nr) * rowb, w_hi, NW, lane16, cmax);
+            } else {
+                cmax = max_chunk_rows(ldsB, nr, a.halo * rowb, wave, NW, lane, a.lv_shift, V, cmax);
+                cmax = max_chunk_rows(ldsB, lo_rows, (slo - wbase) * rowb, w_lo, NW, lane, a.lv_shift, V, cmax);
+                cmax = max_chunk_rows(ldsB, hi_rows, (a.halo + nr) * rowb, w_hi, NW, lane, a.lv_shift, V, cmax);
             }
+            cmax = wave_max_dpp(cmax);
         }
-        for (int i = tid; i < nr; i += T) dmax = max(dmax, (unsigned)(rpS[2 * i + 2] - rpS[2 * i]));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o));
-            dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o));
-        }
-        if (lane == 0) { red[16 + wave] = cmax; red[32 + wave] = dmax; }
+        const unsigned long long any_out = __ballot(outside);
+        // one word per wave: the largest count it fetched (saturating at 2^24: beyond that no item is fast), bit 31 = one of
+        // its staged neighbours is outside the window; sixteen words are read back, wave 0 clears the unused ones
+        if (lane == 63) red[wave] = min(cmax, 0x1000000u) | (any_out != 0ull ? 0x80000000u : 0u);
+        if (wave == 0 && lane >= NW && lane < 16) red[lane] = 0u;
     }
     __syncthreads();
-    unsigned tile_cmax = 0, tile_dmax = 0, tile_out = 0;
-    for (int w = 0; w < NW; ++w) { tile_out |= red[w]; tile_cmax = max(tile_cmax, red[16 + w]); tile_dmax = max(tile_dmax, red[32 + w]); }
-    const unsigned thr = 0xFFFFFFu / (tile_dmax + 1u);   // per-count bound keeping incl+excl < 2^24
-    const bool fast = tile_cmax <= thr && col_in_lds;     // block-uniform
-    const bool all_in = tile_out == 0u;                   // block-uniform: no per-batch window check needed
+    unsigned tile_cmax = 0u, tile_or = 0u;
+    if (!(a.dbg & 16)) {
+        // every thread reads all sixteen words (four broadcast reads in flight: ONE LDS round trip)
+        const uint4* r4 = reinterpret_cast<const uint4*>(red);
+        const uint4 x0 = r4[0], x1 = r4[1], x2 = r4[2], x3 = r4[3];
+        tile_or = (x0.x | x0.y | x0.z | x0.w) | (x1.x | x1.y | x1.z | x1.w) | (x2.x | x2.y | x2.z | x2.w) | (x3.x | x3.y | x3.z | x3.w);
+        const unsigned k = 0x7fffffffu;
+        const unsigned m0 = max(max(x0.x & k, x0.y & k), max(x0.z & k, x0.w & k)), m1 = max(max(x1.x & k, x1.y & k), max(x1.z & k, x1.w & k));
+        const unsigned m2 = max(max(x2.x & k, x2.y & k), max(x2.z & k, x2.w & k)), m3 = max(max(x3.x & k, x3.y & k), max(x3.z & k, x3.w & k));
+        tile_cmax = max(max(m0, m1), max(m2, m3));
+    }
+    tile_cmax = (unsigned)__builtin_amdgcn_readfirstlane((int)tile_cmax);
+    // an item is fast (32-bit sums, float32 quotient) iff (degree + 1) * (largest count of the tile) < 2^24
+    const bool fast_tile = tile_cmax <= 0xFFFFFFu && col_in_lds;                         // block-uniform
+    const bool all_in = __builtin_amdgcn_readfirstlane((int)tile_or) >= 0;               // block-uniform: no per-batch window check needed
 
     // ---- per (row, vector) item: gather neighbours from LDS, divide, store
     {
@@ -630,11 +688,229 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      /
         const int dr = T / V, dc = T - dr * V;
         const int kb = (int)kbase;
         for (int it = tid; it < items; it += T) {
-            const int k0 = rpS[2 * ri] - kb, k1 = rpS[2 * ri + 2] - kb;   // (differences of the low words: lists are < 2^31 entries)
-            const int64_t o = (r0 + ri) * a.s + c0 + c * VEC;
+            const int k0 = rpS[2 * ri] - kb, k1 = (a.dbg & 2) ? k0 : rpS[2 * ri + 2] - kb;   // (differences of the low words: lists are < 2^31 entries)
+            const int64_t o = (int64_t)(r0 + ri) * a.s + c0 + c * VEC;
             const int own_off = (a.halo + ri) * rowb;
             bool done = false;
-            if (fast)
+            const unsigned deg = (unsigned)(k1 - k0);
+            if (fast_tile && ((a.dbg & 8) || (deg < 254u && __umul24(deg + 1u, tile_cmax) <= 0xFFFFFFu)))
+                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
+                              : ps_item_fast<VEC, WEXCL, WPS, true, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
+            if (!done)
+                ps_item_slow<VEC, WEXCL, WPS, Q3, 0>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
+                                                     own_off, o, wbase);
+            c += dc; ri += dr;
+            if (c >= V) { c -= V; ri += 1; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Register-staged tile kernel, second generation (VEC = 4 tables).  What the LDS-DMA experiments taught, applied to
+// the register path (which gets the tile's count bound for free while the vectors pass through the VGPRs):
+//   * EVERY global load of the tile is issued before the first one is waited for: the tile's own rows (up to four
+//     vectors per thread), then -- behind one scalar-load round trip for the first / last row pointer and the reach
+//     words -- the halo rows the lists really reach (reach words of the clustering kernel, 16 rows in all on
+//     gene-shaped data instead of 2 x 16), the neighbour indices and the row pointers; hipcc's counted vmcnt waits
+//     then retire them in issue order while the data moves to LDS;
+//   * one workgroup barrier: the count bound goes through one LDS word per wave (DPP reduction, sixteen broadcast
+//     reads after the barrier), the degree enters per item: an item is fast iff (degree + 1) * bound < 2^24.
+template <bool CHUNKED, bool WEXCL, bool WPS, bool Q3>
+__global__ void __launch_bounds__(1024, 8) ps_tile_v3_kernel(PsArgs a) {
+    extern __shared__ int4 smem4[];
+    constexpr int VEC = 4;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = T >> 6;
+    const int win_cap = a.tile_rows + 2 * a.halo;
+    int* tileL = reinterpret_cast<int*>(smem4);
+    int* colL = tileL + (win_cap + 1) * a.chunk_cols;            // row win_cap is the all-zero padding row
+    int* rpL = colL + a.col_cap;
+    unsigned* red = reinterpret_cast<unsigned*>(rpL + ((a.tile_rows + 1 + 3) & ~3));   // one word per wave (16-byte aligned)
+
+    const int bid = blockIdx.x;
+    int tile, chunk = 0;
+    if (!CHUNKED) {
+        tile = a.tiles_per_xcd ? (bid & 7) * a.tiles_per_xcd + (bid >> 3) : bid;
+    } else {
+        tile = bid / a.n_chunks;
+        chunk = bid - tile * a.n_chunks;
+        if (a.tiles_per_xcd) {
+            const int k = bid >> 3;
+            const int t_local = k / a.n_chunks;
+            chunk = k - t_local * a.n_chunks;
+            tile = (bid & 7) * a.tiles_per_xcd + t_local;
+        }
+    }
+    if (tile >= a.n_tiles) return;
+    const int c0 = chunk * a.chunk_cols;
+    const int cwc = CHUNKED ? min(a.chunk_cols, a.s - c0) : a.s;
+    const int V = cwc / VEC;
+    const int ldw = a.chunk_cols, LV = ldw / VEC;
+    const int lsh = 6 - a.lv_shift;                        // column chunks: log2(LV)
+    const int r0 = tile * a.tile_rows;                     // (n < 2^31)
+    const int nr = min(a.tile_rows, (int)a.n - r0);
+    const int wbase = r0 - a.halo;                         // row that LDS window row 0 stands for (may be negative)
+    const int rowb = ldw * 4;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    for (int i = tid; i < LV; i += T) reinterpret_cast<int4*>(tileL + win_cap * a.chunk_cols)[i] = make_int4(0, 0, 0, 0);
+    const int zero_off = win_cap * a.chunk_cols * 4;
+    int4* win4 = reinterpret_cast<int4*>(tileL);
+
+    // ---- (1) the tile's own rows: up to four vectors per thread, all in flight
+    const char* gtile = reinterpret_cast<const char*>(a.counts + (int64_t)r0 * a.s + c0);
+    const int64_t row_stride = (int64_t)a.s * 4;
+    const int ctot = nr * LV;
+    int4 cv[4];
+    bool cok[4];
+    {
+        // unconditional loads at clamped positions (a predicated load drags exec-mask code and early waits into the
+        // sequence); the predicate acts on the LDS store
+        const int4* g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * T;
+            cok[k] = idx < ctot;
+            const int ic = min(idx, ctot - 1);
+            if (!CHUNKED) g[k] = reinterpret_cast<const int4*>(gtile) + ic;
+            else {
+                const int rr = ic >> lsh, cc = ic & (LV - 1);
+                cok[k] = cok[k] && cc < V;
+                g[k] = reinterpret_cast<const int4*>(gtile + rr * row_stride) + min(cc, V - 1);
+            }
+        }
+        if (a.nt) { cv[0] = nt_load(g[0]); cv[1] = nt_load(g[1]); cv[2] = nt_load(g[2]); cv[3] = nt_load(g[3]); }
+        else      { cv[0] = *g[0]; cv[1] = *g[1]; cv[2] = *g[2]; cv[3] = *g[3]; }
+    }
+
+    // ---- (2) uniform scalars of the tile (scalar loads: they return on lgkmcnt, the vector queue stays untouched)
+    long long kbase, kend;
+    int nlo = a.halo, nhi = a.halo;
+    {
+        const int64_t* pf = a.row_ptr + r0;
+        const int64_t* pl = pf + nr;
+        if (a.reach) {
+            const int b0 = r0 >> 4, bl = (r0 + nr - 1) >> 4;
+            const uint32_t* q0 = a.reach + b0;
+            const uint32_t* q1 = a.reach + min(b0 + 1, bl);
+            const uint32_t* q2 = a.reach + max(bl - 1, b0);
+            const uint32_t* q3 = a.reach + bl;
+            unsigned w0, w1, w2, w3;
+            asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %6, 0x0\n\ts_load_dwordx2 %1, %7, 0x0\n\t"
+                         "s_load_dword %2, %8, 0x0\n\ts_load_dword %3, %9, 0x0\n\t"
+                         "s_load_dword %4, %10, 0x0\n\ts_load_dword %5, %11, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(kbase), "=&s"(kend), "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
+                         : "s"(pf), "s"(pl), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory");
+            // block b reaches (w & 255) rows below row 16 b and (w >> 8 & 255) rows beyond row 16 b + 15
+            const int e = r0 + nr - 1;
+            int lo_need = (int)(w0 & 255u);
+            if (b0 < bl) lo_need = max(lo_need, (int)(w1 & 255u) - 16);
+            int hi_need = ((bl << 4) + 15 + (int)((w3 >> 8) & 255u)) - e;
+            if (b0 < bl) hi_need = max(hi_need, (bl << 4) - 1 + (int)((w2 >> 8) & 255u) - e);
+            nlo = min(max(lo_need, 0), a.halo);
+            nhi = min(max(hi_need, 0), a.halo);
+        } else {
+            asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(kbase), "=&s"(kend) : "s"(pf), "s"(pl) : "memory");
+        }
+    }
+    const int nk = (int)(kend - kbase);
+    const int slo = max(0, r0 - nlo);
+    const int shi = min((int)a.n, r0 + nr + nhi);
+    const int wrows = shi - slo;
+
+    // ---- (3) halo rows: the run below the tile, then the run above it, two vectors per thread
+    const int lo_rows = r0 - slo, hi_rows = shi - (r0 + nr);
+    const int lo_n = lo_rows * LV, hi_n = hi_rows * LV;
+    int4 hv[2];
+    int hdst[2];                                            // LDS vector index, -1: nothing
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + k * T;
+        const bool is_lo = idx < lo_n;
+        const int j = is_lo ? idx : idx - lo_n;            // vector inside its run
+        bool ok = is_lo || j < hi_n;
+        // (clamped: the tile's first vector stands in for a missing one)
+        const char* grun = is_lo ? gtile - lo_rows * row_stride : (ok ? gtile + nr * row_stride : gtile);
+        const int jc = ok ? j : 0;
+        const int ldst = (is_lo ? (slo - wbase) : (a.halo + nr)) * LV + j;
+        const int4* g;
+        if (!CHUNKED) g = reinterpret_cast<const int4*>(grun) + jc;
+        else {
+            const int rr = jc >> lsh, cc = jc & (LV - 1);
+            ok = ok && cc < V;
+            g = reinterpret_cast<const int4*>(grun + rr * row_stride) + min(cc, V - 1);
+        }
+        hdst[k] = ok ? ldst : -1;
+        hv[k] = *g;                                         // (halo rows are another tile's own rows: they may stay in the L2)
+    }
+    // ---- (4) neighbour indices (three per thread) and (5) row pointers (two per thread)
+    const bool col_in_lds = nk <= a.col_cap && nk <= 3 * T;
+    int jv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int kk = tid + k * T; jv[k] = a.col[kbase + (col_in_lds ? min(kk, max(nk - 1, 0)) : 0)]; }
+    int rp_mine[2];                                         // (low words: a tile's lists are < 2^31 entries)
+    rp_mine[0] = reinterpret_cast<const int*>(a.row_ptr + r0 + min(tid, nr))[0];
+    rp_mine[1] = reinterpret_cast<const int*>(a.row_ptr + r0 + min(tid + T, nr))[0];
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
+
+    // ---- retire them in issue order: window vectors to LDS (their maximum on the way), offsets, pointers
+    unsigned cmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (cok[k]) { win4[a.halo * LV + tid + k * T] = cv[k]; cmax = max(cmax, vmax(cv[k])); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (hdst[k] >= 0) { win4[hdst[k]] = hv[k]; cmax = max(cmax, vmax(hv[k])); }
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int kk = tid + k * T;
+        if (col_in_lds && kk < nk) {
+            const int j = jv[k];
+            const bool in = (unsigned)(j - slo) < (unsigned)wrows;
+            outside = outside || !in;
+            colL[kk] = in ? (j - wbase) * rowb : -1 - j;
+        }
+    }
+    if (tid <= nr) rpL[tid] = rp_mine[0] - (int)kbase;
+    if (tid + T <= nr) rpL[tid + T] = rp_mine[1] - (int)kbase;
+    {
+        cmax = wave_max_dpp(cmax);
+        const unsigned long long any_out = __ballot(outside);
+        // one word per wave: its largest count (saturating at 2^24: beyond that no item is fast), bit 31 = one of its
+        // staged neighbours is outside the window; sixteen words are read back, wave 0 clears the unused ones
+        if (lane == 63) red[wave] = min(cmax, 0x1000000u) | (any_out != 0ull ? 0x80000000u : 0u);
+        if (wave == 0 && lane >= NW && lane < 16) red[lane] = 0u;
+    }
+    __syncthreads();
+    unsigned tile_cmax, tile_or;
+    {
+        const uint4* r4 = reinterpret_cast<const uint4*>(red);
+        const uint4 x0 = r4[0], x1 = r4[1], x2 = r4[2], x3 = r4[3];
+        tile_or = (x0.x | x0.y | x0.z | x0.w) | (x1.x | x1.y | x1.z | x1.w) | (x2.x | x2.y | x2.z | x2.w) | (x3.x | x3.y | x3.z | x3.w);
+        const unsigned k = 0x7fffffffu;
+        const unsigned m0 = max(max(x0.x & k, x0.y & k), max(x0.z & k, x0.w & k)), m1 = max(max(x1.x & k, x1.y & k), max(x1.z & k, x1.w & k));
+        const unsigned m2 = max(max(x2.x & k, x2.y & k), max(x2.z & k, x2.w & k)), m3 = max(max(x3.x & k, x3.y & k), max(x3.z & k, x3.w & k));
+        tile_cmax = max(max(m0, m1), max(m2, m3));
+    }
+    tile_cmax = (unsigned)__builtin_amdgcn_readfirstlane((int)tile_cmax);
+    // an item is fast (32-bit sums, float32 quotient) iff (degree + 1) * (largest count of the tile) < 2^24
+    const bool fast_tile = tile_cmax <= 0xFFFFFFu && col_in_lds;                         // block-uniform
+    const bool all_in = __builtin_amdgcn_readfirstlane((int)tile_or) >= 0;               // block-uniform: no per-batch window check needed
+
+    // ---- per (row, vector) item: gather neighbours from LDS, divide, store
+    {
+        const char* tileB = reinterpret_cast<const char*>(tileL);
+        const int items = nr * V;
+        int ri = tid / V, c = tid - ri * V;
+        const int dr = T / V, dc = T - dr * V;
+        for (int it = tid; it < items; it += T) {
+            const int k0 = rpL[ri], k1 = rpL[ri + 1];
+            const int64_t o = (int64_t)(r0 + ri) * a.s + c0 + c * VEC;
+            const int own_off = (a.halo + ri) * rowb;
+            bool done = false;
+            const unsigned deg = (unsigned)(k1 - k0);
+            if (fast_tile && deg < 254u && __umul24(deg + 1u, tile_cmax) <= 0xFFFFFFu)
                 done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
                               : ps_item_fast<VEC, WEXCL, WPS, true, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
             if (!done)
@@ -682,19 +958,36 @@ int launch_ps_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3
     return SDICE_OK;
 }
 
-template <bool WE, bool WP, bool Q3>
+template <bool CH, bool WE, bool WP, bool Q3>
 int launch_ps_dma_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_dma_kernel<WE, WP, Q3>),
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_dma_kernel<CH, WE, WP, Q3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_dma_kernel<WE, WP, Q3>), grid, dim3(threads), lds, a);
+    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_dma_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
     return SDICE_OK;
 }
+template <bool CH>
 int launch_ps_dma(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps, bool q3) {
-    if (wexcl && wps) return q3 ? launch_ps_dma_one<true, true, true>(ctx, a, threads, lds, grid)
-                                : launch_ps_dma_one<true, true, false>(ctx, a, threads, lds, grid);
-    if (wexcl) return launch_ps_dma_one<true, false, false>(ctx, a, threads, lds, grid);
-    return q3 ? launch_ps_dma_one<false, true, true>(ctx, a, threads, lds, grid)
-              : launch_ps_dma_one<false, true, false>(ctx, a, threads, lds, grid);
+    if (wexcl && wps) return q3 ? launch_ps_dma_one<CH, true, true, true>(ctx, a, threads, lds, grid)
+                                : launch_ps_dma_one<CH, true, true, false>(ctx, a, threads, lds, grid);
+    if (wexcl) return launch_ps_dma_one<CH, true, false, false>(ctx, a, threads, lds, grid);
+    return q3 ? launch_ps_dma_one<CH, false, true, true>(ctx, a, threads, lds, grid)
+              : launch_ps_dma_one<CH, false, true, false>(ctx, a, threads, lds, grid);
+}
+
+template <bool CH, bool WE, bool WP, bool Q3>
+int launch_ps_v3_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_v3_kernel<CH, WE, WP, Q3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_v3_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
+    return SDICE_OK;
+}
+template <bool CH>
+int launch_ps_v3(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps, bool q3) {
+    if (wexcl && wps) return q3 ? launch_ps_v3_one<CH, true, true, true>(ctx, a, threads, lds, grid)
+                                : launch_ps_v3_one<CH, true, true, false>(ctx, a, threads, lds, grid);
+    if (wexcl) return launch_ps_v3_one<CH, true, false, false>(ctx, a, threads, lds, grid);
+    return q3 ? launch_ps_v3_one<CH, false, true, true>(ctx, a, threads, lds, grid)
+              : launch_ps_v3_one<CH, false, true, false>(ctx, a, threads, lds, grid);
 }
 
 template <int VEC>
@@ -734,17 +1027,6 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
                          (!d_excl || (uintptr_t)d_excl % 16 == 0);
     const int vec = (s % 4 == 0 && aligned) ? 4 : 1;
     const int abl = (int)ctx->param("ps.ablate", 0);
-    // window by LDS-DMA + halo from the clustering's reach bytes (ps_tile_dma_kernel); the register-staged kernel
-    // serves tables whose rows are not 16-byte vectors and the timing experiments
-    const bool dma = vec == 4 && abl == 0 && ctx->param("ps.dma", 1) != 0;
-    int64_t lds = ctx->param("ps.lds_bytes", dma ? 40 * 1024 : 80 * 1024);   // four (two) workgroups per CU (160 KiB LDS)
-    if (lds > 160 * 1024) lds = 160 * 1024;
-    if (lds < 8 * 1024) lds = 8 * 1024;
-    int threads = (int)ctx->param("ps.threads", dma ? 512 : 1024);
-    threads = (threads / 64) * 64;
-    if (threads < 64) threads = 64;
-    if (threads > 1024) threads = 1024;
-
     int cw = s;
     const int64_t chunk_param = ctx->param("ps.chunk_cols", 0);
     if (chunk_param > 0) cw = (int)chunk_param;
@@ -752,11 +1034,26 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     if (cw > s) cw = s;
     if (vec == 4) cw = (cw / 4) * 4;
     if (cw < vec) cw = vec;
+    // kernel: 0 = second-generation register-staged kernel (ps_tile_v3_kernel, the default), 1 = LDS-DMA kernel
+    // (ps_tile_dma_kernel), 2 = first-generation kernel (ps_tile_kernel; also serves tables whose rows are not 16-byte
+    // vectors, column chunks whose vectors do not divide 64, and the timing experiments)
+    const bool pow2chunk = cw == s || (cw / 4 <= 64 && 64 % (cw / 4) == 0);
+    int kern = (int)ctx->param("ps.dma", 0);
+    if (vec != 4 || abl != 0 || !pow2chunk || kern < 0 || kern > 2) kern = 2;
+    const bool dma = kern == 1;
+    const bool newk = kern != 2;
+    int64_t lds = ctx->param("ps.lds_bytes", 80 * 1024);   // two workgroups per CU (160 KiB LDS)
+    if (lds > 160 * 1024) lds = 160 * 1024;
+    if (lds < 8 * 1024) lds = 8 * 1024;
+    int threads = (int)ctx->param("ps.threads", 1024);
+    threads = (threads / 64) * 64;
+    if (threads < 64) threads = 64;
+    if (threads > 1024) threads = 1024;
 
     // LDS budget (ints): (R + 2H) * cw window + 16 R staged neighbour offsets + (R + 1) row
     // pointers + 8 scratch
-    const int64_t L = lds / 4 - (dma ? 64 : 16);      // (the LDS-DMA kernel keeps 48 per-wave flag words behind the row pointers)
-    const bool have_reach = dma && d_col != nullptr && d_col == ctx->d_col && ctx->reach_n == n && ctx->d_reach != nullptr &&
+    const int64_t L = lds / 4 - (newk ? 64 : 16);      // (the newer kernels keep 16 per-wave words behind the row pointers)
+    const bool have_reach = newk && d_col != nullptr && d_col == ctx->d_col && ctx->reach_n == n && ctx->d_reach != nullptr &&
                             ctx->param("ps.use_reach", 1) != 0;
     int64_t H = ctx->param("ps.halo_rows", -1);
     if (H < 0) {
@@ -771,11 +1068,14 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     // (a software-pipelined persistent variant -- one workgroup per CU, two LDS buffers, next tile's
     //  loads in flight during the gather -- was built and measured 30 % slower: the kernel is VALU-issue
     //  bound, and halving the resident waves costs more than hiding the load latency gains)
+    if (kern == 0 && H > threads / (cw / 4)) H = threads / (cw / 4);    // (two halo vectors per thread)
     const int64_t r_max = 2 * threads;   // (the register-staged kernel keeps two row pointers per thread in registers)
     const int64_t per_row = dma ? 18 : 17;  // 16 staged neighbour offsets + the row pointer (raw int64 in the LDS-DMA kernel)
     int64_t R = ctx->param("ps.tile_rows", 0);
     if (R <= 0) R = (L - (2 * H + 1) * cw) / (cw + per_row);
     if (R > r_max) R = r_max;
+    if (kern == 0 && R > 4 * threads / (cw / 4)) R = 4 * threads / (cw / 4);   // (four vectors of the tile's own rows per thread)
+    if (kern == 0 && R < 1) R = 1;
     while (H > 0 && (R < 8 || (R + 2 * H + 1) * cw + per_row * R > L)) {
         // window does not fit: shrink the halo first (misses fall back to global loads), then the tile
         H = H / 2;
@@ -806,8 +1106,9 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     // the lines shared by two chunks and the halo rows want the L2 (+1.7 % at 2 M x 500): unchunked tables only
     a.nt = ctx->param("ps.nt_loads", 1) != 0 && n_chunks == 1;
     a.reach = use_reach ? ctx->d_reach : nullptr;
-    a.lv_shift = -1;
-    for (int b = 0; b < 16; ++b) if ((cw / 4) == (1 << b)) a.lv_shift = b;
+    a.dbg = (int)ctx->param("ps.dma_ablate", 0);
+    a.lv_shift = 0;                                        // column chunks: log2(row segments per 1 KiB piece)
+    for (int b = 0; b <= 6; ++b) if ((cw / 4) == (64 >> b)) a.lv_shift = b;
     int gx = a.n_tiles;
     a.tiles_per_xcd = 0;
     const bool q3 = ctx->param("ps.quantize3", 0) != 0;
@@ -818,7 +1119,10 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     const size_t lds_bytes = (size_t)lds;
     SD_ARG((int64_t)gx * n_chunks < (int64_t)1 << 31, "grid too large");
     dim3 grid((unsigned)((int64_t)gx * n_chunks));
-    if (dma) return launch_ps_dma(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3);
+    if (kern == 0) return n_chunks == 1 && cw == s ? launch_ps_v3<false>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3)
+                                                   : launch_ps_v3<true>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3);
+    if (dma) return n_chunks == 1 && cw == s ? launch_ps_dma<false>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3)
+                                             : launch_ps_dma<true>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3);
     if (vec == 4) return launch_ps<4>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
     return launch_ps<1>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
 }

@@ -8,6 +8,7 @@ from splicedice_amd import synth
 from splicedice_amd.engine import Context
 import oracle_np as O
 ctx = Context(0)
+KERN = int(os.environ.get("PS_KERN", "0"))
 shapes = [(3000, 100, 1), (5000, 4, 2), (2000, 8, 3), (2000, 16, 4), (1000, 64, 5), (300, 1000, 4), (1500, 260, 6)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
@@ -15,9 +16,9 @@ for n, s, seed in shapes:
     cr, left, right, strand = synth.make_junctions(n, seed, n_chrom=4)
     _, row_ptr, col = O.cluster_csr(cr, left, right, strand)
     counts = synth.make_counts(n, s, seed + 50)
-    ctx.set_param("ps.dma", 0)
+    ctx.set_param("ps.dma", 2)
     ps0, ex0 = ctx.ps(counts, row_ptr, col, want_excl=True)
-    ctx.set_param("ps.dma", 1)
+    ctx.set_param("ps.dma", KERN)
     ps1, ex1 = ctx.ps(counts, row_ptr, col, want_excl=True)
     bad = np.flatnonzero((ex0 != ex1).any(axis=1))
     print(f"n {n} s {s}: {bad.size} rows differ", flush=True)
@@ -37,7 +38,7 @@ for n, s, seed in [(20000, 100, 11), (50000, 36, 12), (30000, 500, 13), (200000,
     counts = synth.make_counts(n, s, seed + 50)
     d_counts, d_ps = ctx.to_device(counts), ctx.empty((n, s), np.float32)
     out = []
-    for dma in (0, 1):
+    for dma in (2, KERN):
         ctx.set_param("ps.dma", dma)
         d_ps.memset(0xff)
         ctx.ps_dev(d_counts, d_rp, d_col, None, d_ps)
