@@ -25,6 +25,7 @@
 //      skips 64-aligned blocks whose block maximum is below it.
 //   5. degree -> exclusive scan (row order) -> fill.
 #include "common.h"
+#include <unistd.h>
 
 int sd_inclusive_max_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, uint64_t* d_out);
 
@@ -456,6 +457,7 @@ int sd_cluster_legacy(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const i
     int64_t reach = 0;
     for (int i = 0; i < 1024; ++i) reach = hp[64 + i] > reach ? hp[64 + i] : reach;
     ctx->cluster_reach = (int)reach;
+    SD_TRY(sd_cluster_check_nnz(ctx, nnz, false));
     if (nnz > ctx->col_cap) {
         if (ctx->d_col) (void)hipFree(ctx->d_col);
         ctx->d_col = nullptr;
@@ -478,7 +480,29 @@ int sd_cluster_legacy(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const i
     return SDICE_OK;
 }
 
-int sd_cluster_resolve(sdice_ctx* ctx);
+int sd_cluster_check_nnz(sdice_ctx* ctx, int64_t nnz, bool host) {
+    int64_t cap = ctx->param("cluster.max_nnz", 0);
+    const char* what = "param cluster.max_nnz";
+    if (cap <= 0) {
+        size_t free_b = 0, total_b = 0;
+        SD_HIP(hipMemGetInfo(&free_b, &total_b));
+        const int64_t held = ctx->col_cap * 4;                       // (the buffer it would replace)
+        cap = (int64_t)((double)(free_b + (size_t)held) * 0.9) / 4;
+        what = "free device memory";
+        if (host) {
+            const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+            const int64_t hcap = pages > 0 && psz > 0 ? (int64_t)pages * psz / 2 / 4 : cap;
+            if (hcap < cap) { cap = hcap; what = "half of the host memory"; }
+        }
+    }
+    if (nnz > cap) {
+        sdice_set_error("sdice_cluster: the neighbour list has %lld entries (%.2f GB), more than %s allows (%lld entries); "
+                        "the junction set is too dense to materialise its overlap lists",
+                        (long long)nnz, (double)nnz * 4e-9, what, (long long)cap);
+        return SDICE_ERR_NOMEM;
+    }
+    return SDICE_OK;
+}
 
 extern "C" int sdice_cluster_col_dev(sdice_ctx* ctx, const int32_t** d_col, int64_t* nnz) {
     SD_ARG(ctx && d_col, "bad arguments");
@@ -511,6 +535,7 @@ extern "C" int sdice_cluster(sdice_ctx* ctx, int64_t n, const int32_t* chrom_ran
     if (rc == SDICE_OK) rc = sdice_h2d(ctx, ds, strand, n);
     int64_t z = 0;
     if (rc == SDICE_OK) rc = sdice_cluster_dev(ctx, n, dc, dl, dr, ds, drow, drp, &z);
+    if (rc == SDICE_OK) rc = sd_cluster_check_nnz(ctx, z, true);        // (the caller is about to hold the list on the host)
     if (rc == SDICE_OK) rc = sdice_d2h(ctx, row_of, drow, n * 4);
     if (rc == SDICE_OK) rc = sdice_d2h(ctx, row_ptr, drp, (n + 1) * 8);
     if (rc == SDICE_OK && nnz) *nnz = z;

@@ -59,6 +59,9 @@ constexpr int64_t FAST_MAX_N = (int64_t)MAX_BUCKETS * BUCKET_MEAN;
 enum : unsigned long long { ST_INVALID = 1, ST_SLOT_OVERFLOW = 2, ST_DUP = 4, ST_COL_OVERFLOW = 8, ST_LOOKBACK = 16 };
 // status block (uint64 words)
 constexpr int SB_FLAGS = 0, SB_NNZ = 2, SB_MAXLEN = 32, SB_REACH = 64, SB_WORDS = 96;
+// word SB_STICKY lies BEHIND the words a chain clears: every flag is also OR-ed into it, and only the call that reports
+// the status clears it -- the failure of an asynchronous chain survives the chains enqueued behind it
+constexpr int SB_STICKY = SB_WORDS, SB_ALLOC_WORDS = SB_WORDS + 8;
 constexpr int SB_SLOTS = 32;
 
 struct FastArgs {
@@ -199,8 +202,11 @@ __global__ void __launch_bounds__(T) bucket_scatter_kernel(FastArgs a) {
         else s_over = 1;
     }
     __syncthreads();
-    if (t == 0 && (s_bad | s_over))
-        atomicOr(&a.sb[SB_FLAGS], (s_bad ? (unsigned long long)ST_INVALID : 0ull) | (s_over ? (unsigned long long)ST_SLOT_OVERFLOW : 0ull));
+    if (t == 0 && (s_bad | s_over)) {
+        const unsigned long long f = (s_bad ? (unsigned long long)ST_INVALID : 0ull) | (s_over ? (unsigned long long)ST_SLOT_OVERFLOW : 0ull);
+        atomicOr(&a.sb[SB_FLAGS], f);
+        atomicOr(&a.sb[SB_STICKY], f);
+    }
 }
 
 // ------------------------------------------------------------------ 3. per-bucket sort, row arrays
@@ -611,7 +617,7 @@ __global__ void __launch_bounds__(SORT_T, 8) bucket_sort_kernel(FastArgs a) {   
     }
     if (dup) s_dup = 1;
     __syncthreads();
-    if (t == 0 && s_dup) atomicOr(&a.sb[SB_FLAGS], (unsigned long long)ST_DUP);
+    if (t == 0 && s_dup) { atomicOr(&a.sb[SB_FLAGS], (unsigned long long)ST_DUP); atomicOr(&a.sb[SB_STICKY], (unsigned long long)ST_DUP); }
 }
 
 // ------------------------------------------------------------------ 4. neighbour lists
@@ -646,7 +652,7 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
         const unsigned long long need = first_p >= 63 ? ~0ull : ((1ull << (first_p + 1)) - 1ull);
         if (empty & need) {
             if (++spins > (1u << 21)) {
-                if (lane == 0) atomicOr(&sb[SB_FLAGS], (unsigned long long)ST_LOOKBACK);
+                if (lane == 0) { atomicOr(&sb[SB_FLAGS], (unsigned long long)ST_LOOKBACK); atomicOr(&sb[SB_STICKY], (unsigned long long)ST_LOOKBACK); }
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -936,7 +942,7 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     if (tile == n_tiles - 1 && t == 0) {
         a.row_ptr[n] = min(base + (int64_t)total, cap);
         a.sb[SB_NNZ] = (unsigned long long)(base + (int64_t)total);
-        if (base + (int64_t)total > cap) atomicOr(&a.sb[SB_FLAGS], (unsigned long long)ST_COL_OVERFLOW);
+        if (base + (int64_t)total > cap) { atomicOr(&a.sb[SB_FLAGS], (unsigned long long)ST_COL_OVERFLOW); atomicOr(&a.sb[SB_STICKY], (unsigned long long)ST_COL_OVERFLOW); }
     }
     if (staged) {
         for (uint32_t k = t; k < total; k += T)
@@ -988,11 +994,12 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
     // The status block is a small persistent allocation of the context (an asynchronous call is
     // resolved later, when the arena may already hold another call's scratch).
     if (!ctx->cluster_sb) {
-        hipError_t e = hipMalloc((void**)&ctx->cluster_sb, (size_t)SB_WORDS * 8);
+        hipError_t e = hipMalloc((void**)&ctx->cluster_sb, (size_t)SB_ALLOC_WORDS * 8);
         if (e != hipSuccess) {
             sdice_set_error("sdice_cluster: hipMalloc of the status block failed: %s", hipGetErrorString(e));
             return SDICE_ERR_NOMEM;
         }
+        SD_HIP(hipMemsetAsync(ctx->cluster_sb, 0, (size_t)SB_ALLOC_WORDS * 8, ctx->stream));
     }
     // zero region: [tile states] (needed by every neighbour run) then [cursor | rank | bmax64]
     const size_t zk4 = (size_t)pl.n_tiles * 8;
@@ -1066,10 +1073,13 @@ int ensure_reach(sdice_ctx* ctx, int64_t n) {       // one word per 16 rows
 }  // namespace
 
 // Fetch the status block of the last fast-path run (synchronises).  Returns the flags.
-static int fast_fetch_status(sdice_ctx* ctx, unsigned long long* flags, int64_t* nnz, int64_t* reach) {
+// (also clears the sticky word: the caller reports what it held)
+static int fast_fetch_status(sdice_ctx* ctx, unsigned long long* flags, int64_t* nnz, int64_t* reach, unsigned long long* sticky = nullptr) {
     int64_t* hp = ctx->h_pinned;
-    SD_HIP(hipMemcpyAsync(hp, ctx->cluster_sb, (size_t)SB_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipMemcpyAsync(hp, ctx->cluster_sb, (size_t)SB_ALLOC_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipMemsetAsync((unsigned long long*)ctx->cluster_sb + SB_STICKY, 0, 8, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
+    if (sticky) *sticky = (unsigned long long)hp[SB_STICKY];
     *flags = (unsigned long long)hp[SB_FLAGS];
     *nnz = hp[SB_NNZ];
     int64_t rc = 0;
@@ -1095,10 +1105,13 @@ static int fast_flags_to_error(unsigned long long flags) {
 int sd_cluster_resolve(sdice_ctx* ctx) {
     if (!ctx->cluster_pending) return SDICE_OK;
     ctx->cluster_pending = false;
-    unsigned long long flags = 0;
+    unsigned long long flags = 0, sticky = 0;
     int64_t nnz = 0, reach = 0;
-    SD_TRY(fast_fetch_status(ctx, &flags, &nnz, &reach));
+    SD_TRY(fast_fetch_status(ctx, &flags, &nnz, &reach, &sticky));
     ctx->nnz = 0;
+    // the sticky word holds the failures of EVERY chain enqueued since the last report (the per-chain words only those of
+    // the last one: a chain re-zeroes them)
+    flags |= sticky;
     SD_TRY(fast_flags_to_error(flags));
     if (flags & (ST_SLOT_OVERFLOW | ST_LOOKBACK)) {
         sdice_set_error("sdice_cluster_dev (asynchronous): %s; call with nnz != NULL (synchronous) "
@@ -1129,9 +1142,12 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
     SD_HIP(hipSetDevice(ctx->device));
-    ctx->cluster_pending = false;
+    // a synchronous call reports what earlier asynchronous chains left behind (it synchronises anyway); an asynchronous
+    // one leaves their status pending: failures accumulate in the sticky word of the status block
+    if (nnz_out && ctx->cluster_pending) SD_TRY(sd_cluster_resolve(ctx));
     ctx->reach_n = 0;
     const bool legacy = n > FAST_MAX_N || ctx->param("cluster.generic", 0) || ctx->param("cluster.legacy", 0);
+    if ((legacy || n == 0) && ctx->cluster_pending) SD_TRY(sd_cluster_resolve(ctx));     // (the generic path synchronises)
     if (legacy || n == 0) return sd_cluster_legacy(ctx, n, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, nnz_out);
     SD_ARG(d_chrom && d_left && d_right && d_strand && d_row_of && d_row_ptr, "NULL pointer");
     ctx->nnz = 0;
@@ -1184,6 +1200,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
     if (flags & (ST_SLOT_OVERFLOW | ST_LOOKBACK))      // (> 8x the mean bucket size between two splitters, or an unexpected dispatch order)
         return sd_cluster_legacy(ctx, n, d_chrom, d_left, d_right, d_strand, d_row_of, d_row_ptr, nnz_out);
     if (flags & ST_COL_OVERFLOW) {
+        SD_TRY(sd_cluster_check_nnz(ctx, nnz, false));
         SD_TRY(ensure_col(ctx, nnz + nnz / 8 + 1024));
         SD_HIP(hipMemsetAsync(pl.zero_base, 0, pl.k4_zero_bytes, ctx->stream));
         // flags, ticket, total and reach start over; the maximum length (words SB_MAXLEN..) stays

@@ -125,6 +125,10 @@ static inline int64_t sd_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b
 
 // status of an asynchronous sdice_cluster_dev (synchronises when one is pending)
 int sd_cluster_resolve(sdice_ctx* ctx);
+// SDICE_ERR_NOMEM (message naming nnz) when a neighbour list of nnz entries exceeds param cluster.max_nnz or, when that
+// is 0, what fits the free device memory (+ the list buffer the context already holds); `host`: also what half of the
+// host's physical memory holds.  Called BEFORE the list is allocated anywhere.
+int sd_cluster_check_nnz(sdice_ctx* ctx, int64_t nnz, bool host);
 
 // ---- internal device-level primitives shared between translation units ----
 // stable LSD radix sort of (key64, val32) pairs; only the bits set in `bit_mask`

@@ -112,8 +112,18 @@ def gen_cluster_big(ctx, rng):
     first = first[rng.permutation(first.size)]
     cr, left, right, strand = (np.ascontiguousarray(cr[first], np.int32), np.ascontiguousarray(left[first], np.int32),
                                np.ascontiguousarray((left + ln)[first], np.int32), np.ascontiguousarray(strand[first], np.int8))
-    if expected_nnz(cr, left, right, strand) > 400_000_000:     # (a dense draw: 2.6 M junctions of up to 40 kb inside 2.6 Mb
-        return None                                             #  would be 5e10 list entries, 200 GB on the host)
+    if expected_nnz(cr, left, right, strand) > 400_000_000:
+        # a dense draw (2.6 M junctions of up to 40 kb inside 2.6 Mb would be 5e10 list entries, 200 GB): the library must
+        # refuse it cleanly under a cap, before it allocates anything of that size on either side
+        from splicedice_amd.engine import SdiceError
+        try:
+            ctx.set_param("cluster.max_nnz", 400_000_000)
+            ctx.cluster(cr, left, right, strand)
+            return f"cluster_big: a list of > 4e8 entries was materialised under cluster.max_nnz = 4e8 (n={first.size} kind={kind})"
+        except SdiceError as e:
+            return None if "neighbour list" in str(e) else f"cluster_big: unexpected error for a dense draw: {e}"
+        finally:
+            ctx.set_param("cluster.max_nnz", 0)
     fast = ctx.cluster(cr, left, right, strand)
     try:
         ctx.set_param("cluster.generic", 1)

@@ -173,6 +173,26 @@ def test_dispatcher_names_and_flags():
     assert a.manifest is None and a.comparison == "vs.tsv"
 
 
+def test_console_entry_point_resolves():
+    """pyproject.toml declares `splicedice = splicedice_amd.__main__:main`, the reference's console
+    name (reference setup.py:200-204): the target must import and be the dispatcher's main."""
+    import importlib
+    import os
+    try:
+        import tomllib as toml          # Python >= 3.11
+    except ImportError:
+        import tomli as toml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        meta = toml.load(f)
+    target = meta["project"]["scripts"]["splicedice"]
+    modname, func = target.split(":")
+    fn = getattr(importlib.import_module(modname), func)
+    from splicedice_amd.__main__ import main
+    assert fn is main
+    assert "splicedice_amd" in meta["tool"]["setuptools"]["packages"]
+
+
 # ----------------------------------------------------------------------------------- shard plan
 def test_shard_plan_clean_cuts_and_halo():
     from oracle import oracle_np as O

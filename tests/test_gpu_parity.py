@@ -186,6 +186,57 @@ def test_cluster_async_and_deferred_errors(ctx):
         fresh.close()
 
 
+def test_cluster_async_error_survives_a_later_chain(ctx):
+    """An asynchronous clustering that failed must still be reported after ANOTHER asynchronous clustering has been
+    enqueued behind it (the later chain re-zeroes the per-chain status words: the failure lives in the sticky word)."""
+    from splicedice_amd.engine import SdiceError
+    n = 20000
+    cr, left, right, strand = synth.make_junctions(n, 51)
+    cr2, left2, right2, strand2 = cr.copy(), left.copy(), right.copy(), strand.copy()
+    cr2[7], left2[7], right2[7], strand2[7] = cr2[11], left2[11], right2[11], strand2[11]
+    good = [ctx.to_device(x) for x in (cr, left, right, strand)]
+    bad = [ctx.to_device(x) for x in (cr2, left2, right2, strand2)]
+    d_row_of, d_row_ptr = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    d_row_of2, d_row_ptr2 = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    ctx.sync()
+    ctx.cluster_dev(*bad, d_row_of, d_row_ptr, sync=False)        # fails on the device
+    ctx.cluster_dev(*good, d_row_of2, d_row_ptr2, sync=False)     # a valid chain behind it
+    with pytest.raises(SdiceError, match="duplicate"):
+        ctx.sync()
+    ctx.sync()                                                    # consumed
+    # ... and a SYNCHRONOUS call behind a failed asynchronous one reports it instead of dropping it
+    ctx.cluster_dev(*bad, d_row_of, d_row_ptr, sync=False)
+    with pytest.raises(SdiceError, match="duplicate"):
+        ctx.cluster_dev(*good, d_row_of2, d_row_ptr2)
+    want = O.cluster_csr(cr, left, right, strand)
+    d_col, nnz = ctx.cluster_dev(*good, d_row_of2, d_row_ptr2)
+    assert nnz == want[2].size and np.array_equal(d_row_ptr2.to_host(), want[1])
+
+
+def test_cluster_list_size_is_bounded(ctx):
+    """A clustering whose neighbour lists exceed the cap ends in a clean SDICE_ERR_NOMEM that names the size, before
+    anything of that size is allocated on the device or the host (the reference degrades gracefully with Python lists,
+    SPLICEDICE.py:230-255; an unbounded np.empty(nnz) / hipMalloc(4 nnz) does not)."""
+    from splicedice_amd.engine import SdiceError
+    crd, ld, rd, sd = synth.make_junctions(3000, 50, n_chrom=1, gene_spacing=30, len_span=200000)
+    want = O.cluster_csr(crd, ld, rd, sd)
+    assert want[2].size > 200_000
+    fresh = type(ctx)(0)
+    try:
+        fresh.set_param("cluster.max_nnz", 100_000)
+        with pytest.raises(SdiceError, match=r"neighbour list.*%d entries" % want[2].size):
+            fresh.cluster(crd, ld, rd, sd)
+        fresh.set_param("cluster.generic", 1)
+        with pytest.raises(SdiceError, match=r"neighbour list.*%d entries" % want[2].size):
+            fresh.cluster(crd, ld, rd, sd)
+        fresh.set_param("cluster.generic", 0)
+        fresh.set_param("cluster.max_nnz", 0)                     # automatic: what HBM and host memory hold
+        got = fresh.cluster(crd, ld, rd, sd)
+        assert np.array_equal(got[2], want[2])
+    finally:
+        fresh.close()
+
+
 def test_cluster_empty_and_invalid(ctx):
     e32 = np.zeros(0, np.int32)
     row_of, row_ptr, col = ctx.cluster(e32, e32, e32, np.zeros(0, np.int8))
