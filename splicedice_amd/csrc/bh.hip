@@ -21,6 +21,9 @@ int sd_inclusive_min_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, u
 size_t sd_bh_cols_scratch(int64_t m, int64_t segs);
 bool sd_bh_cols_supported(int64_t m, int64_t segs);
 int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_cm, double* d_out, int64_t out_pitch);
+bool sd_bh_vector_supported(int64_t n);
+size_t sd_bh_vector_scratch(int64_t n);
+int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, bool masked, double* d_q);
 
 namespace {
 
@@ -249,6 +252,13 @@ extern "C" int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double
     if (m == 0) return SDICE_OK;
     SD_ARG(d_p && d_q, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
+    // bh.vector_path: 0 = by size, 1 = radix path, 2 = sample-sort path (bh_cols.hip, five launches)
+    const int64_t vpath = ctx->param("bh.vector_path", 0);
+    if (vpath != 1 && sd_bh_vector_supported(m)) {
+        SD_TRY(ctx->arena.reserve(sd_bh_vector_scratch(m), ctx->stream));
+        return sd_bh_vector_samplesort(ctx, m, d_p, nullptr, false, d_q);
+    }
+    SD_ARG(vpath != 2, "bh.vector_path = 2 needs 16384 <= m <= 2 Mi values");
     SD_TRY(ctx->arena.reserve((size_t)m * 37 + (size_t)(m / 3072 + 2) * 1024 + (1 << 16), ctx->stream));
     return bh_segments(ctx, m, 1, d_p, d_q);
 }
@@ -259,6 +269,12 @@ extern "C" int sdice_bh_masked_dev(sdice_ctx* ctx, int64_t n, const double* d_p,
     if (n == 0) return SDICE_OK;
     SD_ARG(d_p && d_q, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
+    const int64_t vpath = ctx->param("bh.vector_path", 0);
+    if (vpath != 1 && sd_bh_vector_supported(n)) {
+        SD_TRY(ctx->arena.reserve(sd_bh_vector_scratch(n), ctx->stream));
+        return sd_bh_vector_samplesort(ctx, n, d_p, d_tested, true, d_q);
+    }
+    SD_ARG(vpath != 2, "bh.vector_path = 2 needs 16384 <= n <= 2 Mi values");
     SD_TRY(ctx->arena.reserve((size_t)n * 37 + (size_t)(n / 3072 + 2) * 1024 + (1 << 16), ctx->stream));
     Arena& A = ctx->arena;
     const size_t M = (size_t)n;

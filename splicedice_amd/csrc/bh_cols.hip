@@ -25,6 +25,7 @@
 // end with the group's last, smallest p*m/rank), so the result is bit-identical to the generic path.
 #include "common.h"
 #include <algorithm>
+#include <stdio.h>
 
 namespace {
 
@@ -261,6 +262,53 @@ __device__ __forceinline__ void wave_bitonic(uint64_t (&key)[K], uint32_t (&val)
     }
 }
 
+// the same network in the composite order (key, val): for splitters, which must be ordered among equal keys too
+template <int K>
+__device__ __forceinline__ void wave_bitonic_kv(uint64_t (&key)[K], uint32_t (&val)[K], const int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64 * K; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j >= 1; j >>= 1) {
+            if (j >= K) {
+                const int lm = j / K;
+                const bool lower = (lane & lm) == 0;
+                const bool up = k2 >= 64 * K ? true : (lane & (k2 / K)) == 0;
+                const bool keep_min = lower == up;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint64_t o = shfl_xor_u64(key[k], lm);
+                    const uint32_t ov = (uint32_t)__shfl_xor((int)val[k], lm);
+                    const bool o_less = o < key[k] || (o == key[k] && ov < val[k]);
+                    const bool o_more = o > key[k] || (o == key[k] && ov > val[k]);
+                    const bool take = keep_min ? o_less : o_more;
+                    key[k] = take ? o : key[k];
+                    val[k] = take ? ov : val[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int kp = k ^ j;
+                    if (kp > k) {
+                        bool up;
+                        if (k2 < K) up = (k & k2) == 0;
+                        else if (k2 >= 64 * K) up = true;
+                        else up = (lane & (k2 / K)) == 0;
+                        const bool p_less = key[kp] < key[k] || (key[kp] == key[k] && val[kp] < val[k]);
+                        const bool p_more = key[kp] > key[k] || (key[kp] == key[k] && val[kp] > val[k]);
+                        const bool sw = up ? p_less : p_more;
+                        const uint64_t tk = key[k];
+                        const uint32_t tv = val[k];
+                        key[k] = sw ? key[kp] : tk;
+                        val[k] = sw ? val[kp] : tv;
+                        key[kp] = sw ? tk : key[kp];
+                        val[kp] = sw ? tv : val[kp];
+                    }
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ uint64_t raw_bits(uint64_t key, int64_t rank1, int64_t m) {
     // p_(i) / (i / m), the arithmetic of the generic path (bh.hip bh_raw_kernel)
     const double ps = __longlong_as_double((long long)key);
@@ -481,6 +529,408 @@ __global__ void __launch_bounds__(256) bhs_finish_kernel(BhsArgs a, double* __re
     }
 }
 
+// =====================================================================================================
+// ONE long vector (compare_sample_sets: 1 M p-values; `--multiple_test_correction all`): sample sort in five
+// launches instead of the 29 of the radix path (8 passes x 3 kernels + 5), which were pure launch latency
+// (0.26 ms for 16 MB of algorithmic traffic):
+//   bhv_rank     ranks of a jittered regular sample (8 per bucket) by brute force over the grid;
+//   bhv_count    every 8th ranked sample is a splitter; tile of 4096 values, binary search in LDS, one global atomic
+//                per (tile, bucket); counts the present entries (masked variant);
+//   bhv_scatter  the same search, bucket starts from the counts (every workgroup scans them itself), 12-byte
+//                (key, index) elements land in their bucket;
+//   bhv_bucket   one WORKGROUP per bucket (~4096 values in LDS): a local sample sort into sub-buckets of ~64..128, one
+//                wave per sub-bucket sorts it in registers (wave_bitonic), rank = bucket start + position,
+//                p * m / rank with the generic path's arithmetic, suffix minima inside the sub-bucket and over the
+//                bucket's sub-buckets, partial results scattered to the original positions with the bucket id;
+//   bhv_finish   suffix minima over the bucket minima (every workgroup for itself), min(own, later buckets, 1).
+// Ties are broken by index in every comparison (a vector of ONE repeated value still splits evenly); absent entries
+// (masked variant) carry the key ~0, sort behind every p-value and are counted out of m.  Bit-identical to the radix path.
+struct BhvArgs {
+    const double* p; const uint8_t* tested; int masked;
+    int64_t n;
+    int B, spb, S;
+    uint32_t* rank;        // [S]
+    unsigned* gcount;      // [B]
+    unsigned* cursor;      // [B]
+    unsigned long long* m_eff;
+    uint64_t* keyS; uint32_t* idxS;     // [n] bucketed
+    uint64_t* qpart;       // [n]
+    uint16_t* bid;         // [n]
+    uint64_t* bmin;        // [B]
+    int cap;               // values a bucket workgroup holds in LDS
+    double* q;
+};
+constexpr int BHV_T = 1024;           // threads of every bhv kernel but the ranking
+constexpr int BHV_E = 4;              // values per thread in a count / scatter / finish tile
+
+// absent entries sort behind every p-value (NaN patterns included) and in front of the padding (~0) of the register sorts
+constexpr uint64_t BHV_ABSENT = ~0ull - 1;
+__device__ __forceinline__ uint64_t bhv_key(const BhvArgs& a, int64_t i) {
+    const double v = a.p[i];
+    const bool present = !a.masked || (a.tested ? a.tested[i] != 0 : !(v < 0.0));
+    return present ? key_of(v) : BHV_ABSENT;
+}
+__device__ __forceinline__ int64_t bhv_sample_pos(const BhvArgs& a, int j) {
+    const int64_t lo = (int64_t)j * a.n / a.S, hi = (int64_t)(j + 1) * a.n / a.S;
+    return lo + (int64_t)(hash32((unsigned)j * 2654435761u + 12345u) % (unsigned)(hi - lo));
+}
+
+__global__ void __launch_bounds__(256) bhv_rank_kernel(BhvArgs a) {
+    __shared__ uint64_t jk[256];
+    __shared__ uint32_t ji[256];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 256 + t, j = blockIdx.y * 256 + t;
+    uint64_t ik = 0; uint32_t ii = 0;
+    if (i < a.S) { const int64_t pos = bhv_sample_pos(a, i); ik = bhv_key(a, pos); ii = (uint32_t)pos; }
+    jk[t] = ~0ull; ji[t] = ~0u;
+    if (j < a.S) { const int64_t pos = bhv_sample_pos(a, j); jk[t] = bhv_key(a, pos); ji[t] = (uint32_t)pos; }
+    __syncthreads();
+    if (i >= a.S) return;
+    const int nj = min(256, a.S - (int)blockIdx.y * 256);
+    unsigned cnt = 0;
+#pragma unroll 8
+    for (int q = 0; q < nj; ++q) {
+        const uint64_t k = jk[q];
+        cnt += (k < ik || (k == ik && ji[q] < ii)) ? 1u : 0u;
+    }
+    if (cnt) atomicAdd(&a.rank[i], cnt);
+}
+
+// splitters into LDS: sample s with rank r = spb * (b + 1) is splitter b
+__device__ __forceinline__ void bhv_load_splitters(const BhvArgs& a, uint64_t* sk, uint32_t* si, int tid) {
+    for (int s = tid; s < a.S; s += BHV_T) {
+        const unsigned r = a.rank[s];
+        if (r != 0u && r % (unsigned)a.spb == 0u) {
+            const int b = (int)(r / (unsigned)a.spb) - 1;
+            if (b < a.B - 1) { const int64_t pos = bhv_sample_pos(a, s); sk[b] = bhv_key(a, pos); si[b] = (uint32_t)pos; }
+        }
+    }
+}
+// exclusive scan of up to 1024 counters held one per thread (BHV_T threads); returns this thread's prefix
+__device__ __forceinline__ unsigned bhv_block_excl_scan(unsigned v, unsigned* wsum /*[16]*/, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    unsigned x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    unsigned pre = x - v;
+    for (int k = 0; k < w; ++k) pre += wsum[k];
+    return pre;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(BHV_T) bhv_tile_kernel(BhvArgs a) {
+    extern __shared__ uint64_t smem_v[];
+    uint64_t* sk = smem_v;                                            // [B]
+    uint32_t* si = reinterpret_cast<uint32_t*>(sk + a.B);             // [B]
+    unsigned* hist = reinterpret_cast<unsigned*>(si + a.B);           // [B]
+    unsigned* base = hist + a.B;                                      // [B]
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < a.B; b += BHV_T) hist[b] = 0;
+    bhv_load_splitters(a, sk, si, tid);
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * (BHV_T * BHV_E);
+    uint64_t key[BHV_E];
+    int bkt[BHV_E];
+    unsigned off[BHV_E];
+    unsigned present = 0;
+#pragma unroll
+    for (int q = 0; q < BHV_E; ++q) {
+        const int64_t e = e0 + q * BHV_T + tid;
+        key[q] = e < a.n ? bhv_key(a, e) : 0;
+        present += (e < a.n && key[q] != BHV_ABSENT) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < BHV_E; ++q) {
+        const int64_t e = e0 + q * BHV_T + tid;
+        bkt[q] = -1;
+        if (e < a.n) {
+            bkt[q] = find_bucket(sk, si, a.B - 1, key[q], (uint32_t)e);
+            off[q] = atomicAdd(&hist[bkt[q]], 1u);
+        }
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (int b = tid; b < a.B; b += BHV_T)
+            if (hist[b]) atomicAdd(&a.gcount[b], hist[b]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) present += (unsigned)__shfl_xor((int)present, o);
+        if ((tid & 63) == 0) wsum[tid >> 6] = present;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < BHV_T / 64; ++w) tot += wsum[w];
+            if (tot) atomicAdd(a.m_eff, (unsigned long long)tot);
+        }
+        return;
+    }
+    // bucket starts from the global counts (B <= 1024: one counter per thread), then this tile's run in each bucket
+    const unsigned gc = tid < a.B ? a.gcount[tid] : 0u;
+    const unsigned start = bhv_block_excl_scan(gc, wsum, tid);
+    if (tid < a.B) base[tid] = start + (hist[tid] ? atomicAdd(&a.cursor[tid], hist[tid]) : 0u);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BHV_E; ++q) {
+        if (bkt[q] >= 0) {
+            const int64_t dst = (int64_t)base[bkt[q]] + off[q];
+            a.keyS[dst] = key[q];
+            a.idxS[dst] = (uint32_t)(e0 + q * BHV_T + tid);
+        }
+    }
+}
+
+// a bucket beyond the LDS capacity (practically never): in-place network in HBM by one wave
+__device__ uint64_t bhv_sub_in_lds(uint64_t* ks, uint32_t* is, int n_s, int64_t rank0, int64_t m_eff, int lane) {
+    int P = 1;
+    while (P < n_s) P <<= 1;
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j >= 1; j >>= 1) {
+            for (int t = lane; t < (P >> 1); t += 64) {
+                int i, l;
+                if (j == (k2 >> 1)) { const int blk = t / j, r = t - blk * j; i = blk * k2 + r; l = blk * k2 + k2 - 1 - r; }
+                else { i = ((t & ~(j - 1)) << 1) | (t & (j - 1)); l = i | j; }
+                if (l < n_s) {
+                    const uint64_t ka = ks[i], kb = ks[l];
+                    if (kb < ka) { const uint32_t ia = is[i], ib = is[l]; ks[i] = kb; ks[l] = ka; is[i] = ib; is[l] = ia; }
+                }
+            }
+            __threadfence_block();
+        }
+    }
+    uint64_t carry = ~0ull;
+    for (int c = (n_s - 1) / 64; c >= 0; --c) {
+        const int p = c * 64 + lane;
+        uint64_t x = ~0ull;
+        if (p < n_s) {
+            const int64_t rank1 = rank0 + p + 1;
+            x = rank1 <= m_eff ? raw_bits(ks[p], rank1, m_eff) : 0x7ff0000000000000ull;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = shfl_down_u64(x, o);
+            if (lane + o < 64) x = y < x ? y : x;
+        }
+        x = carry < x ? carry : x;
+        if (p < n_s) ks[p] = x;
+        carry = ((uint64_t)(unsigned)__shfl((int)(unsigned)(x >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)(x & 0xffffffffu), 0);
+    }
+    return carry;
+}
+
+__global__ void __launch_bounds__(BHV_T) bhv_bucket_kernel(BhvArgs a) {
+    extern __shared__ uint64_t smem_b[];
+    // LDS: K[cap] I[cap] K2[cap] I2[cap] SB[cap] + small tables
+    uint64_t* K1 = smem_b;
+    uint64_t* K2 = K1 + a.cap;
+    uint32_t* I1 = reinterpret_cast<uint32_t*>(K2 + a.cap);
+    uint32_t* I2 = I1 + a.cap;
+    uint8_t* SB = reinterpret_cast<uint8_t*>(I2 + a.cap);
+    __shared__ uint64_t ssk[64], smin[64];
+    __shared__ uint32_t ssi[64];
+    __shared__ unsigned scount[64], sstart[65], srank[256];
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int64_t m_eff = (int64_t)*a.m_eff;
+    // bucket start = sum of the counts before it
+    const unsigned gc = tid < a.B ? a.gcount[tid] : 0u;
+    unsigned before = tid < b ? gc : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += (unsigned)__shfl_xor((int)before, o);
+    if (lane == 0) wsum[wave] = before;
+    if (tid < 64) scount[tid] = 0;
+    if (tid < 256) srank[tid] = 0;
+    __syncthreads();
+    unsigned start = 0;
+    for (int w = 0; w < BHV_T / 64; ++w) start += wsum[w];
+    const int n_b = (int)a.gcount[b];
+    if (n_b == 0) { if (tid == 0) a.bmin[b] = ~0ull; return; }
+    if (n_b > a.cap) {
+        // (adversarial input only) the bucket does not fit LDS: its first wave sorts it in place in HBM
+        if (wave == 0) {
+            uint64_t* ks = a.keyS + start; uint32_t* is = a.idxS + start;
+            const uint64_t mn = bhv_sub_in_lds(ks, is, n_b, (int64_t)start, m_eff, lane);
+            __threadfence();
+            for (int p = lane; p < n_b; p += 64) { a.qpart[is[p]] = ks[p]; a.bid[is[p]] = (uint16_t)b; }
+            if (lane == 0) a.bmin[b] = mn;
+        }
+        return;
+    }
+    for (int i = tid; i < n_b; i += BHV_T) { K1[i] = a.keyS[start + i]; I1[i] = a.idxS[start + i]; }
+    // sub-buckets of ~32..64 values: a power of two, at most 64
+    int nsb = 1;
+    while (nsb < 64 && nsb * 40 < n_b) nsb <<= 1;
+    __syncthreads();
+    if (nsb > 1) {
+        // 4 * nsb regular samples (<= 256), ranked by counting (one sample per lane of the first waves, the others as
+        // broadcast reads); the sample of rank 4 (b + 1) is splitter b
+        const int ns = 4 * nsb;
+        const int nsh = 31 - __builtin_clz((unsigned)ns);            // ns is a power of two; j * n_b < 2^21
+        // all threads: thread t counts, for sample t mod ns, the smaller samples among slice t / ns of the sample
+        const int slices = BHV_T / ns;                                // >= 4
+        const int per = ns / slices;                                  // samples per slice (a power of two >= 1)
+        {
+            const int sm = tid & (ns - 1), sl = tid >> nsh;
+            const int pos = (sm * n_b) >> nsh;
+            const uint64_t km = K1[pos];
+            const uint32_t im = I1[pos];
+            unsigned c = 0;
+            for (int j0 = sl * per; j0 < (sl + 1) * per; j0 += 8) {
+                uint64_t kj[8];
+                uint32_t ij[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int pj = (min(j0 + u, ns - 1) * n_b) >> nsh; kj[u] = K1[pj]; ij[u] = I1[pj]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c += (j0 + u < (sl + 1) * per && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
+            }
+            if (c) atomicAdd(&srank[sm], c);
+        }
+        __syncthreads();
+        if (tid < ns) {
+            const unsigned c = srank[tid];
+            if (c != 0u && (c & 3u) == 0u) {
+                const int pos = (tid * n_b) >> nsh;
+                ssk[(c >> 2) - 1] = K1[pos]; ssi[(c >> 2) - 1] = I1[pos];
+            }
+        }
+        __syncthreads();
+    }
+    // classify (each thread up to cap / BHV_T values), count, scatter inside LDS
+    constexpr int EPT = 8;
+    int sub[EPT];
+    unsigned off[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid + q * BHV_T;
+        sub[q] = -1;
+        if (i < n_b) {
+            sub[q] = nsb > 1 ? find_bucket(ssk, ssi, nsb - 1, K1[i], I1[i]) : 0;
+            off[q] = atomicAdd(&scount[sub[q]], 1u);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned c = lane < nsb ? scount[lane] : 0u;
+        unsigned x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+        sstart[lane] = x - c;
+        if (lane == 63) sstart[64] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid + q * BHV_T;
+        if (sub[q] >= 0) {
+            const unsigned d = sstart[sub[q]] + off[q];
+            K2[d] = K1[i]; I2[d] = I1[i]; SB[d] = (uint8_t)sub[q];
+        }
+    }
+    __syncthreads();
+    // every thread ranks its own values inside their sub-bucket by COUNTING the smaller ones (composite (key, index)
+    // order; eight LDS reads in flight per trip; neighbouring threads share a sub-bucket, so the reads are near-broadcasts)
+    // and writes p * m / rank to the sorted position: values to K1, indices to I1 (free since the scatter).
+    // (A register sorting network per sub-bucket cost ~1.4 ds_bpermute per value and stage on the LDS crossbar; one wave
+    //  per sub-bucket left most of the workgroup idle behind chains of LDS round trips.)
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int d = tid + q * BHV_T;
+        if (d < n_b) {
+            const int sb = SB[d];
+            const int s0 = (int)sstart[sb], n_s = (int)scount[sb];
+            const uint64_t km = K2[d];
+            const uint32_t im = I2[d];
+            unsigned c = 0;
+            for (int j0 = 0; j0 < n_s; j0 += 8) {
+                uint64_t kj[8];
+                uint32_t ij[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = s0 + min(j0 + u, n_s - 1); kj[u] = K2[j]; ij[u] = I2[j]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    c += (j0 + u < n_s && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
+            }
+            const int pos = s0 + (int)c;
+            const int64_t rank1 = (int64_t)start + pos + 1;
+            K1[pos] = rank1 <= m_eff ? raw_bits(km, rank1, m_eff) : 0x7ff0000000000000ull;     // absent entries: +inf
+            I1[pos] = im;
+        }
+    }
+    __syncthreads();
+    // suffix minimum over the bucket's sorted positions: thread t owns positions [t * EPT, t * EPT + EPT)
+    {
+        uint64_t v[EPT];
+        uint64_t run = ~0ull;
+#pragma unroll
+        for (int k = EPT - 1; k >= 0; --k) {
+            const int pos = tid * EPT + k;
+            const uint64_t r = pos < n_b ? K1[pos] : ~0ull;
+            run = r < run ? r : run;
+            v[k] = run;
+        }
+        uint64_t x = run;                       // inclusive suffix minimum over the lanes >= this one
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = shfl_down_u64(x, o);
+            if (lane + o < 64) x = y < x ? y : x;
+        }
+        if (lane == 0) smin[wave] = x;          // (smin: one word per wave here)
+        __syncthreads();
+        uint64_t later = ~0ull;                 // minimum over the waves behind this one
+        for (int w = wave + 1; w < BHV_T / 64; ++w) later = smin[w] < later ? smin[w] : later;
+        uint64_t ex = shfl_down_u64(x, 1);      // ... and over the lanes behind this one
+        if (lane == 63) ex = ~0ull;
+        ex = ex < later ? ex : later;
+        if (tid == 0) a.bmin[b] = x < later ? x : later;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int pos = tid * EPT + k;
+            if (pos < n_b) {
+                const uint32_t dst = I1[pos];
+                a.qpart[dst] = v[k] < ex ? v[k] : ex;
+                a.bid[dst] = (uint16_t)b;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BHV_T) bhv_finish_kernel(BhvArgs a) {
+    __shared__ uint64_t sfx[1024];
+    __shared__ uint64_t wmin[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // sfx[b] = minimum of the bucket minima behind b
+    uint64_t x = tid < a.B ? a.bmin[tid] : ~0ull;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = shfl_down_u64(x, o);
+        if (lane + o < 64) x = y < x ? y : x;
+    }
+    if (lane == 0) wmin[wave] = x;          // inclusive suffix minimum of the wave's 64 buckets
+    __syncthreads();
+    uint64_t later_waves = ~0ull;
+    for (int w = wave + 1; w < BHV_T / 64; ++w) later_waves = wmin[w] < later_waves ? wmin[w] : later_waves;
+    uint64_t ex = shfl_down_u64(x, 1);
+    if (lane == 63) ex = ~0ull;
+    sfx[tid] = ex < later_waves ? ex : later_waves;
+    __syncthreads();
+    const int64_t m_eff = (int64_t)*a.m_eff;
+    (void)m_eff;
+    const int64_t e0 = (int64_t)blockIdx.x * (BHV_T * BHV_E);
+#pragma unroll
+    for (int q = 0; q < BHV_E; ++q) {
+        const int64_t e = e0 + q * BHV_T + tid;
+        if (e < a.n) {
+            const uint64_t own = a.qpart[e], later = sfx[a.bid[e]];
+            double v = __longlong_as_double((long long)(own < later ? own : later));
+            if (v > 1.0) v = 1.0;
+            if (a.masked && bhv_key(a, e) == BHV_ABSENT) v = 0.0;      // absent entries get 0 (as the radix path leaves them)
+            a.q[e] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // scratch bytes the sample-sort path needs for `segs` segments of m values (without the transposed input)
@@ -577,5 +1027,54 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
         SD_LAUNCH(ctx, "bhs_finish_kernel", bhs_finish_kernel, dim3((unsigned)gx, (unsigned)sd_ceil_div(cc, (int64_t)32)),
                   dim3(256), 0, b, d_out + c0, out_pitch);
     }
+    return SDICE_OK;
+}
+
+// One vector of n p-values (masked: entries with tested == 0 -- or p < 0 without a mask -- are absent).  Supported sizes:
+// the sample fits the brute-force ranking and a bucket fits LDS.
+bool sd_bh_vector_supported(int64_t n) { return n >= 16384 && n <= ((int64_t)2 << 20); }      // (up to 1024 buckets of 2048 on average)
+size_t sd_bh_vector_scratch(int64_t n) { return (size_t)n * 30 + (1 << 16); }
+
+int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, bool masked, double* d_q) {
+    Arena& A = ctx->arena;
+    BhvArgs a;
+    a.p = d_p; a.tested = d_tested; a.masked = masked ? 1 : 0; a.n = n; a.q = d_q;
+    // buckets of ~2048 values, 16 samples per bucket: a bucket beyond the LDS capacity (6016 = 2.9 x the mean) has a
+    // probability of ~1e-9 (it would be sorted in HBM by one wave)
+    int64_t mean = ctx->param("bhv.mean", 2048);
+    if (mean < 512) mean = 512;
+    if (mean < sd_ceil_div(n, (int64_t)1024)) mean = sd_ceil_div(n, (int64_t)1024);
+    int B = (int)sd_ceil_div(n, mean);
+    if (B < 2) B = 2;
+    if (B > 1024) B = 1024;
+    a.B = B;
+    a.spb = 16;
+    a.S = a.spb * B;
+    a.cap = 6016;                                   // 6016 x 25 B = 150.4 KB of LDS
+    const size_t N = (size_t)n;
+    // one zeroed block: rank[S] | gcount[B] | cursor[B] | m_eff
+    const size_t zwords = (size_t)a.S + 2 * (size_t)B + 4;
+    unsigned* z = (unsigned*)A.alloc(zwords * 4);
+    a.keyS = (uint64_t*)A.alloc(N * 8);
+    a.qpart = (uint64_t*)A.alloc(N * 8);
+    a.bmin = (uint64_t*)A.alloc((size_t)B * 8);
+    a.idxS = (uint32_t*)A.alloc(N * 4);
+    a.bid = (uint16_t*)A.alloc(N * 2);
+    if (!z || !a.keyS || !a.qpart || !a.bmin || !a.idxS || !a.bid) return SDICE_ERR_NOMEM;
+    a.rank = z;
+    a.gcount = z + a.S;
+    a.cursor = a.gcount + B;
+    a.m_eff = (unsigned long long*)(a.cursor + B + ((a.S + 2 * B) & 1));      // 8-byte aligned
+    SD_HIP(hipMemsetAsync(z, 0, zwords * 4, ctx->stream));
+    const unsigned gs = (unsigned)sd_ceil_div(a.S, 256);
+    SD_LAUNCH(ctx, "bhv_rank_kernel", bhv_rank_kernel, dim3(gs, gs), dim3(256), 0, a);
+    const unsigned tiles = (unsigned)sd_ceil_div(n, (int64_t)(BHV_T * BHV_E));
+    const size_t lds_t = (size_t)B * 20;
+    SD_LAUNCH(ctx, "bhv_count_kernel", (bhv_tile_kernel<false>), dim3(tiles), dim3(BHV_T), lds_t, a);
+    SD_LAUNCH(ctx, "bhv_scatter_kernel", (bhv_tile_kernel<true>), dim3(tiles), dim3(BHV_T), lds_t, a);
+    const size_t lds_b = (size_t)a.cap * 25;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bhv_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    SD_LAUNCH(ctx, "bhv_bucket_kernel", bhv_bucket_kernel, dim3((unsigned)B), dim3(BHV_T), lds_b, a);
+    SD_LAUNCH(ctx, "bhv_finish_kernel", bhv_finish_kernel, dim3(tiles), dim3(BHV_T), 0, a);
     return SDICE_OK;
 }

@@ -834,6 +834,59 @@ def test_bh_fuzz(ctx):
         np.testing.assert_allclose(ctx.bh_columns(p), O.bh_columns(p), rtol=1e-14, atol=0)
 
 
+@pytest.mark.parametrize("n", [16384, 16385, 100_000, 1_000_000, 2_097_152])
+def test_bh_vector_samplesort_vs_radix(ctx, n):
+    """the five-launch sample-sort path for one long vector (bh_cols.hip, bhv_*) against the radix path, bit for bit,
+    and the oracle: continuous values, heavy ties (a tenth exactly 1, a block of one value, values ulps apart), zeros,
+    denormals, NaN; then the masked variant (absent entries by flag and by negative p)"""
+    rng = np.random.default_rng(n)
+    p = rng.random(n) ** rng.choice([1, 3, 20])
+    p[rng.random(n) < 0.1] = 1.0
+    p[100:4100] = 0.25                                           # one value, a whole bucket's worth
+    p[5000:5400] = 1.0 - rng.integers(1, 4, size=400) * 2.0 ** -53
+    p[6000:6005] = [0.0, 5e-324, 1e-300, 1.0, 0.5]
+    p = p[rng.permutation(n)]
+    out = {}
+    try:
+        for path in (1, 2):
+            ctx.set_param("bh.vector_path", path)
+            d_p, d_q = ctx.to_device(p), ctx.empty(n, np.float64)
+            ctx.bh_dev(d_p, d_q)
+            out[path] = d_q.to_host()
+        assert np.array_equal(out[1].view(np.uint64), out[2].view(np.uint64))
+        if n <= 100_000:
+            np.testing.assert_allclose(out[2], O.bh_fdr(p), rtol=1e-14, atol=0)
+        # NaN sorts behind every number in both paths
+        pn = p.copy()
+        pn[rng.integers(0, n, size=3)] = np.nan
+        for path in (1, 2):
+            ctx.set_param("bh.vector_path", path)
+            d_p, d_q = ctx.to_device(pn), ctx.empty(n, np.float64)
+            ctx.bh_dev(d_p, d_q)
+            out[path] = d_q.to_host()
+        assert np.array_equal(out[1].view(np.uint64), out[2].view(np.uint64))
+        # masked: a third of the entries absent
+        tested = (rng.random(n) < 0.67).astype(np.uint8)
+        for path in (1, 2):
+            ctx.set_param("bh.vector_path", path)
+            d_p, d_t, d_q = ctx.to_device(p), ctx.to_device(tested), ctx.empty(n, np.float64)
+            ctx.bh_masked_dev(d_p, d_t, d_q)
+            out[path] = d_q.to_host()
+        assert np.array_equal(out[1].view(np.uint64), out[2].view(np.uint64))
+        assert not out[2][tested == 0].any()
+        if n <= 100_000:
+            np.testing.assert_allclose(out[2][tested != 0], O.bh_fdr(p[tested != 0]), rtol=1e-14, atol=0)
+        pm = np.where(tested != 0, p, -1.0)                      # absent = negative p, no flag array
+        for path in (1, 2):
+            ctx.set_param("bh.vector_path", path)
+            d_p, d_q = ctx.to_device(pm), ctx.empty(n, np.float64)
+            ctx.bh_masked_dev(d_p, None, d_q)
+            out[path] = d_q.to_host()
+        assert np.array_equal(out[1].view(np.uint64), out[2].view(np.uint64))
+    finally:
+        ctx.set_param("bh.vector_path", 0)
+
+
 def test_bh_high_word_runs(ctx):
     """keys that agree in their high 32 bits: short runs of distinct values, long runs of one value, long
     runs of distinct values (p-values that differ by a few ulps, as Fisher's "almost 1" results do)"""

@@ -8,10 +8,12 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ctx = Context(0)
 rng = np.random.default_rng(5)
 p = rng.random(m) ** 2
+p[rng.random(m) < 0.1] = 1.0
 tested = (rng.random(m) < 0.95).astype(np.uint8)
 d_p, d_t, d_q = ctx.to_device(p), ctx.to_device(tested), ctx.empty(m, np.float64)
 for rep in range(2):
-    for path in (1,):
+    for path, mean in ((1, 0), (2, 0)):
+        ctx.set_param('bh.vector_path', path)
         ctx.prof_enable(0)
         for _ in range(3):
             ctx.bh_masked_dev(d_p, d_t, d_q)
@@ -25,4 +27,4 @@ for rep in range(2):
         ctx.sync()
         r = {k.replace("_kernel", ""): round(v[1] / 5 * 1000, 1) for k, v in ctx.prof_report().items()}
         ctx.prof_enable(0)
-        print(f"rep {rep} path {path}: {ms:.4f} ms  {json.dumps(r)}", flush=True)
+        print(f"rep {rep} path {path} (1 = radix, 2 = sample sort): {ms:.4f} ms  {json.dumps(r)}", flush=True)
