@@ -6,7 +6,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W  # N ranks, one per GPU
 
 Workloads (BASELINE.json configs):
-  quant   (default; config 2) : 1M junctions x 100 samples int32 counts resident in HBM.
+  quant   (default) : 2M junctions x 500 samples int32 counts resident in HBM -- the size north_star quotes its target
+          on ("a synthetic 2M-junction x 500-sample count matrix"); BASELINE config 2 (1M x 100) rides under "also".
           One step = the whole quant device path on the rank's junction shard:
           sdice_cluster_dev (sort + overlap lists) + sdice_ps_dev (exclusion sums + PS).
           metric = PS-matrix entries/s.
@@ -33,9 +34,9 @@ library's stream inside the timed region (profiling mode 2 records only that ker
 sample, on rank 0 at N=1 only; it is a reported baseline, never the thing measured above.
 
 At N=1 the line also carries "also": the same measurement (value, roofline, cpu_baseline, verify) for
-the north-star size (quant 2M x 500) and for BASELINE configs 3, 4 (one GPU's shard) and 5 (one GPU's
-shard), a few steps each (--no-also skips them).  Their big tables are one seeded host block repeated
-down the device matrix, so that generation stays bounded; the headline workload is generated whole.
+BASELINE configs 2 (quant 1M x 100), 3, 4 (one GPU's shard) and 5 (one GPU's shard), a few steps each
+(--no-also skips them).  The big tables (the headline's included) are one seeded host block of 200 000 rows
+repeated down the device matrix, so that generation stays bounded.
 """
 import argparse
 import json
@@ -58,12 +59,13 @@ from splicedice_amd import synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: measured float4-copy ceiling (SURVEY 8(d) asks for both denominators)
 F64_WAVE_INSTS_PER_S = 5.25e11   # measured f64 FMA issue rate (tools/mb/microbench.hip: 33.6e12 lane-FMAs/s over 1024 SIMDs)
+F64_WAVE_INSTS_SPEC = 6.14e11    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 instruction (the guide's clock; the chip holds less under load)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)      # (a 0.37 ms step: 20 steps end before the clocks have settled, +3 %)
+    ap.add_argument("--steps", type=int, default=100)      # (a 2 ms step at the default size; short runs end before the clocks have settled)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["quant", "compare", "pairwise", "e2e"], default="quant")
     # (long names only: under torch.distributed.run a short "--n" is swallowed by the launcher's parser)
@@ -156,8 +158,12 @@ class QuantWorkload:
     dtype = "int32 counts -> f32 PS"
     kernel = "ps_tile_kernel"
 
+    DEFAULT_N, DEFAULT_S, DEFAULT_BLOCK = 2_000_000, 500, 200_000      # north_star's target size
+
     def __init__(self, ctx, rank, n, s, block_rows=0):
-        self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
+        if not n and not s and not block_rows:
+            block_rows = self.DEFAULT_BLOCK
+        self.ctx, self.n, self.s = ctx, n or self.DEFAULT_N, s or self.DEFAULT_S
         n, s = self.n, self.s
         t = time.time()
         self.junc = synth.make_junctions(n, 2 + 1000 * rank)          # this rank's chromosome group
@@ -231,9 +237,9 @@ class ShardedQuantWorkload(QuantWorkload):
     name = "quant: cluster + PS, one dataset sharded over the ranks"
 
     def __init__(self, ctx, rank, world, n, s, strong=False):
-        self.ctx, self.s = ctx, s or 100
+        self.ctx, self.s = ctx, s or self.DEFAULT_S
         self.strong = strong
-        self.n_total = (n or 1_000_000) * (1 if strong else world)
+        self.n_total = (n or self.DEFAULT_N) * (1 if strong else world)
         s = self.s
         t = time.time()
         cr, l, r, st = synth.make_junctions(self.n_total, 2)          # the N = 1 dataset, identical on every rank
@@ -243,9 +249,13 @@ class ShardedQuantWorkload(QuantWorkload):
         self.junc = tuple(np.ascontiguousarray(x[mine]) for x in (cr, l, r, st))
         self.n = n_own = int(mine.sum())
         assert n_own == self.row_hi - self.row_lo
-        counts = synth.make_counts_rows(self.row_lo, self.row_hi, s, 20)     # rows of the shared table, output order
+        # rows of the shared table, output order: row r of the table is row r mod 200 000 of one seeded block (bounded
+        # generation time; every rank derives the same table)
+        blk = synth.make_counts(min(self.n_total, self.DEFAULT_BLOCK), s, 20)
+        counts = blk[np.arange(self.row_lo, self.row_hi) % blk.shape[0]]
+        del blk
         self.gen_s = time.time() - t
-        self.tiled = False
+        self.tiled = self.n_total > self.DEFAULT_BLOCK
         self.d_j = [ctx.to_device(x) for x in self.junc]
         self.d_row_of, self.d_row_ptr = ctx.empty(max(n_own, 1), np.int32), ctx.empty(n_own + 1, np.int64)
         self.d_counts = ctx.to_device(counts if n_own else np.zeros((1, s), np.int32))
@@ -260,7 +270,7 @@ class ShardedQuantWorkload(QuantWorkload):
     def describe(self):
         d = super().describe()
         d["workload"] = (f"quant {self.n_total} junctions x {self.s} samples in total "
-                         f"({'the BASELINE config 2 dataset' if self.strong else 'one BASELINE config 2 dataset per GPU'}), "
+                         f"({'the N = 1 dataset' if self.strong else 'N x the N = 1 dataset'}), "
                          f"one junction set cut at chromosome boundaries into {self.world} row ranges, cluster+PS on each")
         d["junctions_total"] = self.n_total
         d["rows_per_rank"] = [b[3] - b[2] for b in self.ranges]
@@ -526,14 +536,33 @@ class E2EWorkload(QuantWorkload):
 WORKLOADS = {"quant": QuantWorkload, "compare": CompareWorkload, "pairwise": PairwiseWorkload, "e2e": E2EWorkload}
 
 
+KERNEL_SOURCES = {"quant": ["ps.hip"], "compare": ["ranksum.hip"], "pairwise": ["fisher.hip"], "e2e": ["ranksum.hip"]}
+
+
+def kernel_source_sha16(workload):
+    """sha256 (first 16 hex digits) of the source file(s) of the workload's dominant kernel: a PMC pass in
+    profiles/pmc_traffic.json is only quoted while the kernel it measured is the kernel that runs"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[workload]:
+        with open(os.path.join(REPO, "splicedice_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profiles(workload, n, s):
-    """(HBM bytes per launch of the dominant kernel, provenance) from the committed rocprofv3 PMC passes:
-    the counters are collected in runs of their own (profiles/), not while this line is measured."""
+    """(HBM bytes per launch of the dominant kernel or None, provenance) from the committed rocprofv3 PMC passes:
+    the counters are collected in runs of their own (profiles/), not while this line is measured.  A pass taken on
+    an older version of the kernel's source is NOT quoted (traffic: null, the note says why)."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
+        sha = kernel_source_sha16(workload)
         with open(path) as fh:
             for rec in json.load(fh):
                 if rec["workload"] == workload and rec["n"] == n and rec["s"] == s:
+                    if rec.get("src_sha16") != sha:
+                        return None, (f"stale profile: {rec.get('source', path)} was taken on source {rec.get('src_sha16', '(unstamped)')}, "
+                                      f"the kernel source is now {sha}")
                     return rec["hbm_bytes_per_launch"], "committed PMC pass: " + rec.get("source", path)
     except (OSError, ValueError, KeyError):
         pass
@@ -614,9 +643,12 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
                 pv = json.load(fh)
             if pv["n"] == wl.n and pv["s"] == wl.s:
                 rate = pv["SQ_INSTS_VALU_per_launch"] / (avg_ms * 1e-3)
-                roofline["valu_f64"] = {"achieved": rate, "peak": F64_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s",
-                                        "frac": rate / F64_WAVE_INSTS_PER_S, "active_lanes_of_64": pv["active_lanes_of_64"],
-                                        "source": pv["source"]}
+                lanes = pv["active_lanes_of_64"]
+                roofline["valu_f64"] = {"achieved": rate, "peak": F64_WAVE_INSTS_SPEC, "unit": "wave64 VALU instructions/s (all VALU, f64 and not)",
+                                        "frac": rate / F64_WAVE_INSTS_SPEC, "peak_measured_fma_loop": F64_WAVE_INSTS_PER_S,
+                                        "frac_of_measured": rate / F64_WAVE_INSTS_PER_S, "active_lanes_of_64": lanes,
+                                        "useful_lane_frac": rate / F64_WAVE_INSTS_SPEC * lanes / 64.0,
+                                        "stale": pv.get("src_sha16") != kernel_source_sha16("pairwise"), "source": pv["source"]}
         except (OSError, ValueError, KeyError):
             pass
     v = None
@@ -645,7 +677,7 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
 
 # what "also" reports at N=1: (key, workload class, n, s, rows of the repeated host block, steps, CPU sample)
 ALSO = [
-    ("quant_2m500", "quant", 2_000_000, 500, 200_000, 20, 100_000),         # the north-star size
+    ("quant_c2", "quant", 1_000_000, 100, 1_000_000, 200, 100_000),        # BASELINE config 2 (generated whole)
     ("compare_c3", "compare", 1_000_000, 100, 200_000, 30, 30_000),        # BASELINE config 3
     ("pairwise_c4_shard", "pairwise", 25_000, 200, 0, 4, 10),              # config 4, one GPU's shard of 8
     ("e2e_c5_shard", "e2e", 625_000, 1000, 125_000, 10, 12_000),            # config 5, one GPU's shard of 8
