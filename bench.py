@@ -16,7 +16,10 @@ Workloads (BASELINE.json configs):
   pairwise (config 4 per-GPU shard) : 25k junctions x 200 samples; step = exclusion sums +
           sdice_fisher_pairs_dev + BH per pair column; metric = p-values/s.
   e2e     (config 5 per-GPU shard)  : 625k junctions x 1000 samples; step = cluster + PS + quantise
-          + rank-sum (500 v 500) + [RCCL all-gather of p-values at N>1] + BH; metric = PS entries/s.
+          + rank-sum (500 v 500) + BH; metric = PS entries/s.
+  N > 1, pairwise / e2e: ONE dataset (N x the per-GPU size; N = 8: configs 4 / 5) cut by the library's shard plan;
+          the step is the product's sharded pipeline (distributed.PairwiseShard / CompareShard): device-side packing,
+          RCCL all-to-all twice + column BH (pairwise), ONE RCCL all-gather of the packed per-junction table + BH (e2e).
 
 Multi-GPU (quant): ONE dataset of N x 1 M junctions is cut into N row ranges at chromosome boundaries
 (zero halo; the ranges differ by a fraction of a per cent) and every rank clusters + quantifies its own
@@ -340,7 +343,7 @@ class CompareWorkload:
 
     def step(self):
         self.ctx.ranksum_dev(self.d_ps, self.d_g1, self.d_g2, self.out)
-        self.ctx.bh_dev(self.out["p"], self.d_q)       # BH over all rows (untested rows carry p = 0 here)
+        self.ctx.bh_masked_dev(self.out["p"], self.out["tested"], self.d_q)     # BH over the tested rows, as the product does
 
     def describe(self):
         return {"workload": f"compare_sample_sets {self.n} junctions, {self.g1.size} v {self.g2.size} (BASELINE config 3), "
@@ -444,7 +447,6 @@ class E2EWorkload(QuantWorkload):
     """
     name = "quant + compare_sample_sets end to end"
     kernel = "ranksum_count_kernel"
-    needs_comm = True
 
     def __init__(self, ctx, rank, n, s, block_rows=0):
         # config 5 is 5M junctions x 1000 samples over 8 GPUs -> 625k junctions per GPU
@@ -456,26 +458,11 @@ class E2EWorkload(QuantWorkload):
         self.out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
                         med1=ctx.empty(n, np.float32), med2=ctx.empty(n, np.float32), mean1=ctx.empty(n, np.float32),
                         mean2=ctx.empty(n, np.float32), delta=ctx.empty(n, np.float32))
-        self.world = 1
-        self.d_p_all = None
         self.d_q = ctx.empty(n, np.float64)
-        self.collective = "none (1 GPU)"
+        self.collective = "none (1 GPU; N > 1: ShardedE2EWorkload)"
         big = max(self.g1.size, self.g2.size)
         self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
         self.alg_bytes = (4.0 * s + 28.0) * n           # rank-sum: 4*S_sel + 28 B per junction
-
-    def setup_comm(self, dist, world):
-        self.world = world
-        try:
-            uid = self.ctx.comm_unique_id() if dist.rank == 0 else None
-            self.ctx.comm_init(dist.bcast_bytes(uid, 128), dist.rank, world)
-            self.d_p_all = self.ctx.empty(self.n * world, np.float64)
-            self.d_q = self.ctx.empty(self.n * world, np.float64)
-            self.collective = f"RCCL all-gather of {self.n * 8} B of p-values per rank, inside every step"
-        except Exception as e:
-            if os.environ.get("SDICE_BENCH_DEVICE") is None:
-                raise                                   # a real multi-GPU run must not lose its exchange step
-            self.collective = f"skipped (one-GPU rehearsal): {str(e)[:120]}"
 
     def step(self):
         self.ctx.set_param("ps.quantize3", 1)           # the '.3f' round trip rides on the PS store
@@ -484,11 +471,7 @@ class E2EWorkload(QuantWorkload):
         finally:
             self.ctx.set_param("ps.quantize3", 0)
         self.ctx.ranksum_dev(self.d_ps, self.d_g1, self.d_g2, self.out)
-        if self.d_p_all is not None:
-            self.ctx.allgather_dev(self.out["p"], self.d_p_all)
-            self.ctx.bh_dev(self.d_p_all, self.d_q)
-        else:
-            self.ctx.bh_dev(self.out["p"], self.d_q)    # untested rows carry p = 0 (same amount of work)
+        self.ctx.bh_masked_dev(self.out["p"], self.out["tested"], self.d_q)     # BH over the tested rows, as the product does
 
     def describe(self):
         return {"workload": f"quant + compare end to end, {self.n} junctions x {self.s} samples per GPU "
@@ -531,6 +514,189 @@ class E2EWorkload(QuantWorkload):
         return {"value": m * self.s / dt, "unit": self.unit, "cores": 1, "kind": "port",
                 "sample": f"{m} junctions x {self.s} samples: oracle get_clusters + calculate_psi + '.3f' round trip + "
                           f"compare_rows (scipy ranksums per row) + BH, {dt:.1f} s"}
+
+
+class _RefusedComm:
+    """stands in for the RCCL communicator in the one-GPU rehearsal of the N>1 control flow (RCCL refuses two ranks on
+    one device): blocks stay where they are, the line reports the collective as refused"""
+    device = True
+
+    def __init__(self, rank, world, why):
+        self.rank, self.world, self.why = rank, world, why
+
+    def allgather(self, x):
+        out = x.ctx.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), x.dtype).zero()
+        return out
+
+    def alltoall(self, x):
+        return x
+
+    def allsum(self, v):
+        return int(v)
+
+
+def _device_comm(ctx, dist, world):
+    """-> (communicator, note): the library's RCCL communicator; in the one-GPU rehearsal a stand-in"""
+    from splicedice_amd import distributed
+    err = None
+    try:
+        comm = distributed.RcclComm(ctx, dist.rank, world, dist.bcast_bytes)
+    except Exception as e:                                   # noqa: BLE001
+        comm, err = None, str(e)[:200]
+    if not dist.all_ok(err is None):
+        if os.environ.get("SDICE_BENCH_DEVICE") is None:
+            raise RuntimeError(f"RCCL communicator: {err or 'failed on another rank'}")   # a real multi-GPU run must not lose its exchange
+        return _RefusedComm(dist.rank, world, err), f"refused (one-GPU rehearsal): {err or 'failed on another rank'}"
+    return comm, None
+
+
+def _tiled_rows(block, lo, hi):
+    """rows [lo, hi) of the table whose row r is row r mod len(block) of one seeded block (every rank derives the same table)"""
+    return np.ascontiguousarray(block[np.arange(lo, hi) % block.shape[0]])
+
+
+class ShardedPairwiseWorkload:
+    """N > 1, `pairwise`: ONE junction set of N x 25 000 junctions x 200 samples (N = 8: BASELINE config 4) cut by the
+    library's shard plan (sdice_shard_plan: clean cuts); every rank holds ITS count rows only.  step = the product's
+    sharded pipeline (distributed.PairwiseShard.step): exclusion sums + Fisher on the rank's rows, device-side packing,
+    RCCL all-to-all (rows -> pair columns), BH down complete columns, all-to-all back, unpack."""
+    name = "pairwise, one dataset sharded over the ranks"
+    metric = PairwiseWorkload.metric
+    unit = PairwiseWorkload.unit
+    dtype = PairwiseWorkload.dtype
+    kernel = "fisher_pairs_kernel"
+
+    def __init__(self, ctx, dist, world, n, s):
+        from splicedice_amd import distributed, shard
+        self.ctx, self.world, self.s = ctx, world, s or 200
+        self.n_total = (n or 25_000) * world
+        s = self.s
+        t = time.time()
+        junc = synth.make_junctions(self.n_total, 4)             # identical on every rank
+        row_of, self.row_ptr, self.col = ctx.cluster(*junc)       # replicated clustering (SURVEY 8(e): it is milliseconds)
+        self.plan = shard.shard_plan(self.row_ptr, self.col, world)
+        part = self.plan[dist.rank]
+        blk = synth.make_counts(min(self.n_total, 50_000), s, 40)
+        ext = _tiled_rows(blk, part["ext_lo"], part["ext_hi"])
+        self.gen_s = time.time() - t
+        self.comm, self.comm_note = _device_comm(ctx, dist, world)
+        self.shard = distributed.PairwiseShard(ctx, self.comm, self.n_total, s, self.plan, "pairwise", "fisher")
+        rp, cl = shard.local_csr(self.row_ptr, self.col, part)
+        self.shard.load(ext, rp, cl)
+        self.n = part["own_hi"] - part["own_lo"]
+        self.pairs = s * (s - 1) // 2
+        self.units = self.n * self.pairs
+        self.alg_bytes = 8.0 * self.n * self.pairs + 12.0 * self.n * s
+        self.ext, self.part = ext, part
+
+    def step(self):
+        self.shard.step()
+
+    def describe(self):
+        return {"workload": f"pairwise {self.n_total} junctions x {self.s} samples in total over {self.world} ranks "
+                            f"(BASELINE config 4 is 200k junctions over 8 GPUs), one junction set cut by sdice_shard_plan: "
+                            f"exclusion sums + Fisher + pack + all-to-all + BH per pair column + all-to-all back",
+                "junctions_total": self.n_total, "rows_per_rank": [q["own_hi"] - q["own_lo"] for q in self.plan],
+                "samples": self.s, "collective": self.comm_note or "RCCL all-to-all (grouped send/recv), twice per step",
+                "collectives": self.shard.timed_collectives() if self.comm_note is None else None}
+
+    def verify(self):
+        """raw Fisher p-values of a few of the rank's rows against the oracle (the corrected matrix needs every rank's rows)"""
+        from oracle import oracle_np as O
+        from splicedice_amd import distributed
+        sh = distributed.PairwiseShard(self.ctx, distributed.SingleComm(), self.n_total, self.s, self.plan[self.comm.rank: self.comm.rank + 1],
+                                       "none", "fisher")
+        ok = True
+        try:
+            from splicedice_amd import shard as _shard
+            rp, cl = _shard.local_csr(self.row_ptr, self.col, self.part)
+            sh.load(self.ext, rp, cl)
+            sh.step()
+            p = sh.result()
+            a0 = self.part["own_lo"] - self.part["ext_lo"]
+            m, cols = min(2, self.n), 12
+            _, excl = O.calculate_psi_vectorised(self.ext, rp, cl)
+            want = O.fisher_pairs(self.ext[a0: a0 + m, :cols], excl[a0: a0 + m, :cols])
+            idx = [i * self.s - i * (i + 1) // 2 + (j - i - 1) for i in range(cols - 1) for j in range(i + 1, cols)]
+            ok = bool(np.allclose(p[:m][:, idx], want, rtol=1e-9, atol=0))
+        finally:
+            sh.free()
+        return ok, 2 * 66
+
+    def cpu_baseline(self, sample):
+        return None
+
+
+class ShardedE2EWorkload:
+    """N > 1, quant + compare end to end: ONE junction set of N x 625 000 junctions x 1000 samples (N = 8: BASELINE
+    config 5) cut by the library's shard plan.  step = clustering of the whole set (replicated on every rank: it is
+    milliseconds) + the product's sharded pipeline (distributed.CompareShard.step): PS with the '.3f' round
+    trip on the rank's rows, rank-sum into ONE packed per-junction block, ONE RCCL all-gather of that block (29 B per
+    junction), BH over the gathered p-values."""
+    name = "quant + compare_sample_sets end to end, one dataset sharded over the ranks"
+    metric = QuantWorkload.metric
+    unit = QuantWorkload.unit
+    dtype = QuantWorkload.dtype
+    kernel = "ranksum_count_kernel"
+
+    def __init__(self, ctx, dist, world, n, s):
+        from splicedice_amd import distributed, shard
+        self.ctx, self.world, self.s = ctx, world, s or 1000
+        self.n_total = (n or 625_000) * world
+        s, nt = self.s, self.n_total
+        t = time.time()
+        self.junc = synth.make_junctions(nt, 5)
+        self.d_j = [ctx.to_device(x) for x in self.junc]
+        self.d_row_of, self.d_row_ptr = ctx.empty(nt, np.int32), ctx.empty(nt + 1, np.int64)
+        d_col, self.nnz = ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr)
+        row_ptr, col = self.d_row_ptr.to_host(), d_col.to_host()
+        self.plan = shard.shard_plan(row_ptr, col, world)
+        part = self.plan[dist.rank]
+        blk = synth.make_counts(min(nt, 125_000), s, 20)
+        ext = _tiled_rows(blk, part["ext_lo"], part["ext_hi"])
+        del blk
+        self.gen_s = time.time() - t
+        self.g1, self.g2 = np.arange(0, s // 2, dtype=np.int32), np.arange(s // 2, s, dtype=np.int32)
+        self.comm, self.comm_note = _device_comm(ctx, dist, world)
+        self.shard = distributed.CompareShard(ctx, self.comm, nt, s, self.plan, self.g1, self.g2)
+        rp, cl = shard.local_csr(row_ptr, col, part)
+        self.shard.load(ext, rp, cl)
+        self.n = part["own_hi"] - part["own_lo"]
+        self.units = self.n * s
+        self.alg_bytes = (4.0 * s + 28.0) * self.n
+        big = max(self.g1.size, self.g2.size)
+        self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
+        self.part = part
+        del ext, row_ptr, col
+
+    def step(self):
+        self.ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr, sync=False)      # replicated, asynchronous
+        self.shard.step()
+
+    def describe(self):
+        _, block = self.shard.off, self.shard.block
+        return {"workload": f"quant + compare end to end, {self.n_total} junctions x {self.s} samples in total over {self.world} ranks "
+                            f"(BASELINE config 5 is 5M x 1000 over 8 GPUs), one junction set cut by sdice_shard_plan: cluster "
+                            f"(replicated) + PS + quantise + rank-sum + ONE all-gather of the per-junction table + BH",
+                "junctions_total": self.n_total, "rows_per_rank": [q["own_hi"] - q["own_lo"] for q in self.plan],
+                "samples": self.s, "avg_overlap_degree": round(self.nnz / self.n_total, 2),
+                "collective": self.comm_note or f"ONE RCCL all-gather of {block} B per rank (the packed per-junction table) per step"}
+
+    def verify(self):
+        from oracle import oracle_np as O
+        m = min(300, self.n)
+        first = self.part["own_lo"] - self.part["ext_lo"]
+        ps = self.shard.d_ps.offset(first * self.s, (m, self.s)).to_host()
+        want = O.compare_rows(ps, self.g1, self.g2)          # the device's own quantised PS rows
+        got = {name: v.offset(0, (m,)).to_host() for name, v in self.shard.views.items()}
+        t = want["tested"].astype(bool)
+        ok = np.array_equal(got["tested"], want["tested"]) and np.array_equal(got["z"][t], want["z"][t]) \
+            and np.allclose(got["p"][t], want["p"][t], rtol=1e-9, atol=0) \
+            and all(np.array_equal(got[k][t], want[k][t]) for k in ("med1", "med2", "mean1", "mean2", "delta"))
+        return bool(ok), m
+
+    def cpu_baseline(self, sample):
+        return None
 
 
 WORKLOADS = {"quant": QuantWorkload, "compare": CompareWorkload, "pairwise": PairwiseWorkload, "e2e": E2EWorkload}
@@ -701,13 +867,15 @@ def main():
     ctx = Context(int(forced) if forced is not None else (dist.local_rank if args.gpus > 1 else 0))
     sharded = args.gpus > 1 and args.workload == "quant"
     strong = sharded and args.strong
+    product_sharded = args.gpus > 1 and args.workload in ("pairwise", "e2e")
     if sharded:
         wl = ShardedQuantWorkload(ctx, dist.rank, args.gpus, args.n, args.s, strong=strong)
+    elif product_sharded:
+        # ONE dataset cut by the library's shard plan, the product's sharded pipeline inside every step
+        wl = (ShardedPairwiseWorkload if args.workload == "pairwise" else ShardedE2EWorkload)(ctx, dist, args.gpus, args.n, args.s)
     else:
         wl = WORKLOADS[args.workload](ctx, dist.rank, args.n, args.s)
     wl.key = args.workload
-    if args.gpus > 1 and getattr(wl, "needs_comm", False):
-        wl.setup_comm(dist, args.gpus)          # this workload has a real exchange step inside every step
 
     elapsed, roofline, verify = measure(ctx, wl, dist, args.steps, args.warmup, args.gpus, not args.no_verify)
     failed = bool(verify and not verify["ok"])
@@ -718,7 +886,7 @@ def main():
         dist.barrier()
 
     allgather = None
-    if args.gpus > 1 and not sharded and not getattr(wl, "needs_comm", False):
+    if args.gpus > 1 and not sharded and not product_sharded:
         # data-plane collective: RCCL all-gather of a per-junction result table (8 B per junction); every rank
         # goes through the same control-plane calls whatever fails where
         err = None
@@ -775,7 +943,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "verify": verify, "allgather": allgather,
             "ps_allgather": ps_allgather,
             "rccl_ranks": args.gpus if any(c and c.get("ok") for c in (ps_allgather, allgather)) or
-            (args.gpus > 1 and getattr(wl, "d_p_all", None) is not None) else (0 if args.gpus > 1 else None),
+            (product_sharded and getattr(wl, "comm_note", "x") is None) else (0 if args.gpus > 1 else None),
             "device": info["name"].strip(), "gen_seconds": round(wl.gen_s, 1),
         }
 

@@ -47,6 +47,9 @@ class SingleComm:
     def alltoall(self, x):
         return x
 
+    def allsum(self, value):
+        return int(value)
+
 
 class GlooComm:
     """Host-side collectives over an initialised torch.distributed (gloo) process group."""
@@ -73,6 +76,13 @@ class GlooComm:
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
         return np.stack([o.numpy()[self.rank] for o in outs])
+
+    def allsum(self, value):
+        """sum of one integer over the ranks (error counts: every rank must take the same decision)"""
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t[0])
 
 
 class RcclComm:
@@ -112,6 +122,36 @@ class RcclComm:
         self.ctx.alltoall_dev(x, recv, x.nbytes // self.world)
         return recv
 
+    def allsum(self, value):
+        return int(self.allgather(np.asarray([int(value)], dtype=np.int64)).sum())
+
+
+def stat_layout(m):
+    """The per-junction table of one rank (m rows, padded) as ONE byte block for ONE all-gather (north_star: "a single
+    RCCL all-gather ... to reassemble the output tables"): name -> (byte offset, dtype); every vector starts at a
+    multiple of 16 bytes.  -> (offsets, block bytes)"""
+    off, at = {}, 0
+    for name, dt in zip(STAT_NAMES, _STAT_DTYPES):
+        off[name] = (at, np.dtype(dt))
+        at += (m * np.dtype(dt).itemsize + 15) // 16 * 16
+    return off, at
+
+
+def pack_stats_host(stats, m):
+    off, nbytes = stat_layout(m)
+    buf = np.zeros(nbytes, dtype=np.uint8)
+    for name, (at, dt) in off.items():
+        buf[at: at + m * dt.itemsize] = np.ascontiguousarray(stats[name], dtype=dt).view(np.uint8)
+    return buf
+
+
+def unpack_stats_host(gathered, m, world):
+    """[world * block bytes] -> name -> array of world * m entries (rank blocks concatenated)"""
+    off, nbytes = stat_layout(m)
+    blocks = np.asarray(gathered, dtype=np.uint8).reshape(world, nbytes)
+    return {name: np.concatenate([blocks[r, at: at + m * dt.itemsize].view(dt) for r in range(world)])
+            for name, (at, dt) in off.items()}
+
 
 def _own_slice(counts_ext, n, part):
     """the caller hands over rows [ext_lo, ext_hi); a full [n, s] table (single-process callers) is cut here"""
@@ -133,38 +173,80 @@ def _bh_masked_host(engine, p, tested):
 
 
 def shard_stats(engine, counts_ext, rp, cl, first, k, g1, g2, pad_to=None):
-    """PS -> '.3f' quantise -> rank-sum for rows [first, first + k) of one shard (with its halo rows).
-    -> dict name -> array of length pad_to (default k), zero beyond k.  Device engine: device arrays, the
-    PS shard is produced, quantised and consumed in HBM; host engine (CPU test double): numpy arrays."""
+    """(host engines: the CPU test double)  PS -> '.3f' quantise -> rank-sum for rows [first, first + k) of one shard
+    (with its halo rows) -> dict name -> array of length pad_to (default k), zero beyond k."""
     pad_to = k if pad_to is None else pad_to
-    if not hasattr(engine, "ps_dev"):
-        out = {name: np.zeros(pad_to, dt) for name, dt in zip(STAT_NAMES, _STAT_DTYPES)}
-        if k:
-            ps = engine.quantize3(engine.ps(counts_ext, rp, cl))   # the _allPS.tsv text round trip (SURVEY 0.5)
-            r = engine.ranksum(ps[first: first + k], g1, g2)
-            for name in STAT_NAMES:
-                out[name][:k] = r[name]
-        return out
-    out = {}
-    for name, dt in zip(STAT_NAMES, _STAT_DTYPES):
-        out[name] = engine.empty(max(pad_to, 1), dt).zero()
+    out = {name: np.zeros(pad_to, dt) for name, dt in zip(STAT_NAMES, _STAT_DTYPES)}
     if k:
-        n_ext, s = counts_ext.shape
-        d_counts = engine.to_device(counts_ext, np.int32)
-        d_rp = engine.to_device(rp, np.int64)
-        d_cl = engine.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
-        d_ps = engine.empty((n_ext, s), np.float32)
-        engine.set_param("ps.quantize3", 1)          # the '.3f' round trip is fused into the PS store
-        try:
-            engine.ps_dev(d_counts, d_rp, d_cl, None, d_ps)
-        finally:
-            engine.set_param("ps.quantize3", 0)
-        d_g1, d_g2 = engine.to_device(g1, np.int32), engine.to_device(g2, np.int32)
-        engine.ranksum_dev(d_ps.offset(first * s, (k, s)), d_g1, d_g2, {name: out[name].offset(0, (k,)) for name in STAT_NAMES})
-        engine.sync()
-        for a in (d_counts, d_rp, d_cl, d_ps, d_g1, d_g2):
-            a.free()
+        ps = engine.quantize3(engine.ps(counts_ext, rp, cl))   # the _allPS.tsv text round trip (SURVEY 0.5)
+        r = engine.ranksum(ps[first: first + k], g1, g2)
+        for name in STAT_NAMES:
+            out[name][:k] = r[name]
     return out
+
+
+class CompareShard:
+    """One rank's part of quant -> compare_sample_sets, resident in HBM (device engines).
+
+    load() uploads the rank's count rows and its local CSR once; step() is device work only: PS with the '.3f'
+    round trip fused into the store, rank-sum into ONE packed block (stat_layout), ONE all-gather of that block,
+    p / tested made contiguous with two strided copies, Benjamini-Hochberg over the gathered vector
+    (sdice_bh_masked_dev: padding and untested rows are absent); result() downloads and drops the padding.
+    bench.py --workload e2e --gpus N times exactly this step (plus the replicated clustering)."""
+
+    def __init__(self, engine, comm, n, s, plan, g1, g2):
+        self.e, self.comm, self.n, self.s, self.plan = engine, comm, n, s, plan
+        part = plan[comm.rank]
+        self.lo, self.hi, self.elo = part["own_lo"], part["own_hi"], part["ext_lo"]
+        self.k = self.hi - self.lo
+        self.m = max(max(p["own_hi"] - p["own_lo"] for p in plan), 1)
+        self.off, self.block = stat_layout(self.m)
+        from .engine import DeviceArray
+        self.packed = engine.empty(self.block, np.uint8).zero()
+        self.views = {name: DeviceArray(engine, (self.m,), dt, ptr=self.packed.ptr + at, owned=False)
+                      for name, (at, dt) in self.off.items()}
+        self.d_g1, self.d_g2 = engine.to_device(g1, np.int32), engine.to_device(g2, np.int32)
+        w = comm.world
+        self.d_p_all, self.d_t_all = engine.empty(w * self.m, np.float64), engine.empty(w * self.m, np.uint8)
+        self.d_q = engine.empty(w * self.m, np.float64)
+        self.recv = None
+        self.d_counts = self.d_rp = self.d_cl = self.d_ps = None
+
+    def load(self, counts_ext, rp, cl):
+        e = self.e
+        if self.k:
+            self.d_counts = e.to_device(np.ascontiguousarray(counts_ext), np.int32)
+            self.d_rp = e.to_device(rp, np.int64)
+            self.d_cl = e.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
+            self.d_ps = e.empty(self.d_counts.shape, np.float32)
+
+    def step(self):
+        e, k, m, w = self.e, self.k, self.m, self.comm.world
+        if k:
+            e.set_param("ps.quantize3", 1)          # the '.3f' round trip is fused into the PS store
+            try:
+                e.ps_dev(self.d_counts, self.d_rp, self.d_cl, None, self.d_ps)
+            finally:
+                e.set_param("ps.quantize3", 0)
+            first = self.lo - self.elo
+            e.ranksum_dev(self.d_ps.offset(first * self.s, (k, self.s)), self.d_g1, self.d_g2,
+                          {name: v.offset(0, (k,)) for name, v in self.views.items()})
+        self.recv = self.comm.allgather(self.packed)                  # ONE collective: world x block bytes
+        at_p, at_t = self.off["p"][0], self.off["tested"][0]
+        e.copy2d_dev(self.d_p_all.ptr, m * 8, self.recv.ptr + at_p, self.block, m * 8, w)      # rank blocks -> one vector
+        e.copy2d_dev(self.d_t_all.ptr, m, self.recv.ptr + at_t, self.block, m, w)
+        e.bh_masked_dev(self.d_p_all, self.d_t_all, self.d_q)
+
+    def result(self):
+        host = unpack_stats_host(self.recv.to_host(), self.m, self.comm.world)
+        host["corrected"] = self.d_q.to_host()
+        return host
+
+    def free(self):
+        for a in (self.d_counts, self.d_rp, self.d_cl, self.d_ps, self.d_g1, self.d_g2, self.packed, self.d_p_all,
+                  self.d_t_all, self.d_q):
+            if a is not None:
+                a.free()
 
 
 def quant_compare_sharded(engine, comm, counts_ext, row_ptr, col, g1, g2, plan=None):
@@ -173,7 +255,7 @@ def quant_compare_sharded(engine, comm, counts_ext, row_ptr, col, g1, g2, plan=N
 
     Returns dict(tested, p, z, corrected, med1, med2, mean1, mean2, delta) for ALL n rows, identical
     on every rank, plus plan.  `engine`: the HIP Context (device path) or a host double with
-    ps / quantize3 / ranksum / bh.
+    ps / quantize3 / ranksum / bh.  The per-junction table crosses the ranks as ONE packed block in ONE all-gather.
     """
     n = row_ptr.size - 1
     plan = plan or shard.shard_plan(row_ptr, col, comm.world)
@@ -183,20 +265,22 @@ def quant_compare_sharded(engine, comm, counts_ext, row_ptr, col, g1, g2, plan=N
     max_rows = max(max(p["own_hi"] - p["own_lo"] for p in plan), 1)
     rp, cl = shard.local_csr(row_ptr, col, part) if k else (np.zeros(1, np.int64), np.zeros(0, np.int32))
     ext = np.ascontiguousarray(_own_slice(counts_ext, n, part)) if k else counts_ext[:0]
-    stats = shard_stats(engine, ext, rp, cl, lo - elo, k, g1, g2, pad_to=max_rows)
-    dev = _is_dev(stats["p"])
-    if dev and not comm.device:
-        stats = {name: a.to_host() for name, a in stats.items()}
-        dev = False
-    gathered = {name: comm.allgather(stats[name]) for name in STAT_NAMES}       # [world * max_rows] each
-    if dev:
-        d_q = engine.empty(comm.world * max_rows, np.float64)
-        engine.bh_masked_dev(gathered["p"], gathered["tested"], d_q)
-        host = {name: gathered[name].to_host() for name in STAT_NAMES}
-        host["corrected"] = d_q.to_host()
+    if hasattr(engine, "ps_dev") and comm.device:
+        sh = CompareShard(engine, comm, n, ext.shape[1] if k else len(g1) + len(g2), plan, g1, g2)
+        try:
+            sh.load(ext, rp, cl)
+            sh.step()
+            engine.sync()
+            host = sh.result()
+        finally:
+            sh.free()
     else:
-        host = dict(gathered)
-        host["corrected"] = _bh_masked_host(engine, gathered["p"], gathered["tested"])
+        if hasattr(engine, "ps_dev"):
+            raise NotImplementedError("a device engine needs a device communicator (RcclComm / SingleComm)")
+        stats = shard_stats(engine, ext, rp, cl, lo - elo, k, g1, g2, pad_to=max_rows)
+        gathered = comm.allgather(pack_stats_host(stats, max_rows))             # ONE collective
+        host = unpack_stats_host(gathered, max_rows, comm.world)
+        host["corrected"] = _bh_masked_host(engine, host["p"], host["tested"])
     out = {}
     for name, a in host.items():                                                # drop the padding: rows in global order
         out[name] = np.concatenate([a[r * max_rows: r * max_rows + plan[r]["own_hi"] - plan[r]["own_lo"]]
@@ -222,12 +306,29 @@ def pair_column_ranges(pairs, world):
     return [(q * pairs // world, (q + 1) * pairs // world) for q in range(world)]
 
 
-def _pairwise_host(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction):
+CHI2_ZERO_MSG = "The internally computed table of expected frequencies has a zero element"
+
+
+def _chi2_abort(comm, n_bad, n_tables):
+    """scipy.stats.chi2_contingency raises on the first table with an empty row or column and the reference run dies
+    with it (pairwise_fisher.py:167-179): every rank takes the same decision from the global count"""
+    total = comm.allsum(n_bad)
+    if total:
+        raise ValueError(f"{CHI2_ZERO_MSG} ({total} of {n_tables} sample-pair tables have an empty row or column)")
+
+
+def _pairwise_host(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, test="fisher"):
+    n_bad = 0
     if k:
         excl = engine.ps(ext, rp, cl, want_excl=True, want_ps=False)
-        p = engine.fisher_pairs(ext[a0: a0 + k], excl[a0: a0 + k])
+        if test == "chi2":
+            p, n_bad = engine.chi2_pairs(ext[a0: a0 + k], excl[a0: a0 + k])
+        else:
+            p = engine.fisher_pairs(ext[a0: a0 + k], excl[a0: a0 + k])
     else:
         p = np.zeros((0, pairs), dtype=np.float64)
+    if test == "chi2":
+        _chi2_abort(comm, n_bad, n * pairs)
     rows_of = [q["own_hi"] - q["own_lo"] for q in plan]
     maxk = max(max(rows_of), 1)
     if correction == "pairwise" and pairs > 0:
@@ -258,73 +359,138 @@ def _pairwise_host(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction)
     return p
 
 
-def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction):
-    s = ext.shape[1]
-    rows_of = [q["own_hi"] - q["own_lo"] for q in plan]
-    maxk = max(max(rows_of), 1)
-    d_p = engine.empty((max(k, 1), max(pairs, 1)), np.float64)
-    if k and pairs:
-        d_counts = engine.to_device(ext, np.int32)
-        d_rp = engine.to_device(rp, np.int64)
-        d_cl = engine.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
-        d_excl = engine.empty(ext.shape, np.int64)
-        engine.ps_dev(d_counts, d_rp, d_cl, d_excl, None)
-        engine.fisher_pairs_dev(d_counts.offset(a0 * s, (k, s)), d_excl.offset(a0 * s, (k, s)), d_p.offset(0, (k, pairs)))
-        engine.sync()
-        for a in (d_counts, d_rp, d_cl, d_excl):
-            a.free()
-    if correction == "pairwise" and pairs > 0:
-        ranges = pair_column_ranges(pairs, comm.world)
-        maxw = max(max(b - a for a, b in ranges), 1)
-        blk = maxk * maxw * 8
-        send = engine.empty((comm.world, maxk, maxw), np.float64).zero()
-        for q, (a, b) in enumerate(ranges):                   # pack my rows of rank q's columns (device, strided)
-            if k and b > a:
-                engine.copy2d_dev(send.ptr + q * blk, maxw * 8, d_p.ptr + a * 8, pairs * 8, (b - a) * 8, k)
-        got = comm.alltoall(send)
-        a, b = ranges[comm.rank]
-        w = b - a
-        mine = engine.empty((max(n, 1), max(w, 1)), np.float64)
-        at = 0
-        for r in range(comm.world):                           # rank r's rows of MY columns -> one [n, w] table
-            if rows_of[r] and w:
-                engine.copy2d_dev(mine.ptr + at * w * 8, w * 8, got.ptr + r * blk, maxw * 8, w * 8, rows_of[r])
-            at += rows_of[r]
-        if n and w:
-            engine.bh_columns_dev(mine.offset(0, (n, w)))
-        back, at = engine.empty((comm.world, maxk, maxw), np.float64).zero(), 0
-        for r in range(comm.world):
-            if rows_of[r] and w:
-                engine.copy2d_dev(back.ptr + r * blk, maxw * 8, mine.ptr + at * w * 8, w * 8, w * 8, rows_of[r])
-            at += rows_of[r]
-        got = comm.alltoall(back)
-        for q, (a, b) in enumerate(ranges):                   # corrected values back into my rows
-            if k and b > a:
-                engine.copy2d_dev(d_p.ptr + a * 8, pairs * 8, got.ptr + q * blk, maxw * 8, (b - a) * 8, k)
-    elif correction == "all" and pairs > 0:
-        pad = engine.empty((maxk, pairs), np.float64).memset(0xBF)     # 0xBFBF... is a negative double: "absent"
-        if k:
-            engine.copy2d_dev(pad.ptr, pairs * 8, d_p.ptr, pairs * 8, pairs * 8, k)
-        everything = comm.allgather(pad)
-        d_q = engine.empty(everything.shape, np.float64)
-        engine.bh_masked_dev(everything, None, d_q)
-        if k:
-            engine.copy2d_dev(d_p.ptr, pairs * 8, d_q.ptr + comm.rank * maxk * pairs * 8, pairs * 8, pairs * 8, k)
-    engine.sync()
-    return d_p.offset(0, (k, pairs)).to_host() if k and pairs else np.zeros((k, pairs), dtype=np.float64)
+class PairwiseShard:
+    """One rank's part of `pairwise`, resident in HBM (device engines): load() uploads the rank's count rows and local
+    CSR once; step() is device work only -- exclusion sums, the per-pair test of the rank's rows, and the correction:
+    "pairwise" packs the p-value matrix into per-rank column blocks ON THE DEVICE (sdice_copy2d_dev), all-to-all,
+    column BH on complete columns, all-to-all back, unpack; "all" all-gathers the raw matrix and ranks it redundantly
+    (sdice_bh_masked_dev); "none" needs no exchange.  bench.py --workload pairwise --gpus N times exactly this step."""
+
+    def __init__(self, engine, comm, n, s, plan, correction="pairwise", test="fisher"):
+        self.e, self.comm, self.n, self.s, self.plan = engine, comm, n, s, plan
+        self.correction, self.test = correction, test
+        part = plan[comm.rank]
+        self.lo, self.hi, self.elo = part["own_lo"], part["own_hi"], part["ext_lo"]
+        self.k = self.hi - self.lo
+        self.pairs = s * (s - 1) // 2
+        self.rows_of = [q["own_hi"] - q["own_lo"] for q in plan]
+        self.maxk = max(max(self.rows_of), 1)
+        self.d_p = engine.empty((max(self.k, 1), max(self.pairs, 1)), np.float64)
+        self.d_counts = self.d_rp = self.d_cl = self.d_excl = None
+        self.d_bad = engine.empty(1, np.int64) if test == "chi2" else None
+        self.ms = {}                                          # per-collective times of the last timed_collectives()
+
+    def load(self, counts_ext, rp, cl):
+        e = self.e
+        if self.k and self.pairs:
+            self.d_counts = e.to_device(np.ascontiguousarray(counts_ext), np.int32)
+            self.d_rp = e.to_device(rp, np.int64)
+            self.d_cl = e.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
+            self.d_excl = e.empty(self.d_counts.shape, np.int64)
+
+    def step(self):
+        e, comm, k, n, s, pairs = self.e, self.comm, self.k, self.n, self.s, self.pairs
+        a0, d_p, maxk, rows_of = self.lo - self.elo, self.d_p, self.maxk, self.rows_of
+        n_bad = 0
+        if k and pairs:
+            e.ps_dev(self.d_counts, self.d_rp, self.d_cl, self.d_excl, None)
+            inc, exc = self.d_counts.offset(a0 * s, (k, s)), self.d_excl.offset(a0 * s, (k, s))
+            if self.test == "chi2":
+                e.chi2_pairs_dev(inc, exc, d_p.offset(0, (k, pairs)), self.d_bad)
+                n_bad = int(self.d_bad.to_host()[0])
+            else:
+                e.fisher_pairs_dev(inc, exc, d_p.offset(0, (k, pairs)))
+        if self.test == "chi2":
+            _chi2_abort(comm, n_bad, n * pairs)
+        if self.correction == "pairwise" and pairs > 0:
+            ranges = pair_column_ranges(pairs, comm.world)
+            maxw = max(max(b - a for a, b in ranges), 1)
+            blk = maxk * maxw * 8
+            send = e.empty((comm.world, maxk, maxw), np.float64).zero()
+            for q, (a, b) in enumerate(ranges):               # pack my rows of rank q's columns (device, strided)
+                if k and b > a:
+                    e.copy2d_dev(send.ptr + q * blk, maxw * 8, d_p.ptr + a * 8, pairs * 8, (b - a) * 8, k)
+            got = comm.alltoall(send)
+            a, b = ranges[comm.rank]
+            w = b - a
+            mine = e.empty((max(n, 1), max(w, 1)), np.float64)
+            at = 0
+            for r in range(comm.world):                       # rank r's rows of MY columns -> one [n, w] table
+                if rows_of[r] and w:
+                    e.copy2d_dev(mine.ptr + at * w * 8, w * 8, got.ptr + r * blk, maxw * 8, w * 8, rows_of[r])
+                at += rows_of[r]
+            if n and w:
+                e.bh_columns_dev(mine.offset(0, (n, w)))
+            back, at = e.empty((comm.world, maxk, maxw), np.float64).zero(), 0
+            for r in range(comm.world):
+                if rows_of[r] and w:
+                    e.copy2d_dev(back.ptr + r * blk, maxw * 8, mine.ptr + at * w * 8, w * 8, w * 8, rows_of[r])
+                at += rows_of[r]
+            got2 = comm.alltoall(back)
+            for q, (a, b) in enumerate(ranges):               # corrected values back into my rows
+                if k and b > a:
+                    e.copy2d_dev(d_p.ptr + a * 8, pairs * 8, got2.ptr + q * blk, maxw * 8, (b - a) * 8, k)
+            self._a2a_bufs = (send, back)                     # (kept for timed_collectives)
+        elif self.correction == "all" and pairs > 0:
+            pad = e.empty((maxk, pairs), np.float64).memset(0xBF)     # 0xBFBF... is a negative double: "absent"
+            if k:
+                e.copy2d_dev(pad.ptr, pairs * 8, d_p.ptr, pairs * 8, pairs * 8, k)
+            everything = comm.allgather(pad)
+            d_q = e.empty(everything.shape, np.float64)
+            e.bh_masked_dev(everything, None, d_q)
+            if k:
+                e.copy2d_dev(d_p.ptr, pairs * 8, d_q.ptr + comm.rank * maxk * pairs * 8, pairs * 8, pairs * 8, k)
+
+    def timed_collectives(self, reps=3):
+        """ms per all-to-all of the step's block shape, timed alone (after a step)"""
+        bufs = getattr(self, "_a2a_bufs", None)
+        if not bufs:
+            return {}
+        e = self.e
+        self.comm.alltoall(bufs[0])
+        e.sync()
+        e.timer_start()
+        for _ in range(reps):
+            self.comm.alltoall(bufs[0])
+        ms = e.timer_stop() / reps
+        return {"alltoall_ms": ms, "alltoall_bytes_per_rank": int(bufs[0].nbytes), "alltoalls_per_step": 2}
+
+    def result(self):
+        self.e.sync()
+        k, pairs = self.k, self.pairs
+        return self.d_p.offset(0, (k, pairs)).to_host() if k and pairs else np.zeros((k, pairs), dtype=np.float64)
+
+    def free(self):
+        for a in (self.d_counts, self.d_rp, self.d_cl, self.d_excl, self.d_p, self.d_bad):
+            if a is not None:
+                a.free()
 
 
-def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwise", plan=None):
+def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, test="fisher"):
+    sh = PairwiseShard(engine, comm, n, ext.shape[1], plan, correction, test)
+    try:
+        sh.load(ext, rp, cl)
+        sh.step()
+        return sh.result()
+    finally:
+        sh.free()
+
+
+def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwise", plan=None, test="fisher"):
     """`pairwise` with junction rows sharded over ranks.
 
     counts_ext: int32 rows [ext_lo, ext_hi) of this rank's shard in row order; CSR over all rows.
     Every rank computes the exclusion sums and the s(s-1)/2 Fisher p-values of ITS rows; the
     correction modes are the reference's (pairwise_fisher.py:182-193): "pairwise" (BH down every pair
-    column over all junctions), "all" (one BH over the whole matrix), "none".
+    column over all junctions), "all" (one BH over the whole matrix), "none".  test = "chi2": the Yates-corrected
+    chi-square of --chi2 (pairwise_fisher.py:133-136) on the same shards; a table with a zero expected frequency anywhere
+    aborts the run on every rank, as the reference's chi2_contingency does.
     Returns dict(p=[k, pairs] for this rank's own rows, own=(lo, hi), plan=...).
     """
     if correction not in ("pairwise", "all", "none"):
         raise ValueError("correction must be pairwise | all | none")
+    if test not in ("fisher", "chi2"):
+        raise ValueError("test must be fisher | chi2")
     n = row_ptr.size - 1
     plan = plan or shard.shard_plan(row_ptr, col, comm.world)
     part = plan[comm.rank]
@@ -336,5 +502,5 @@ def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwis
     rp, cl = shard.local_csr(row_ptr, col, part) if k else (np.zeros(1, np.int64), np.zeros(0, np.int32))
     dev = hasattr(engine, "fisher_pairs_dev") and comm.device
     fn = _pairwise_dev if dev else _pairwise_host
-    p = fn(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction)
+    p = fn(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction, test)
     return dict(p=p, own=(lo, hi), plan=plan)

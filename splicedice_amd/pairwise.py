@@ -140,14 +140,14 @@ def run_with(args, ctx=None):
     own_ctx = ctx is None
     ctx = ctx if ctx is not None else Context(L.local_rank)
     header = "clusterID\t" + "\t".join(columns) + "\n"
-    if L.world > 1 and totaln and pairs and not args.chi2:
+    if L.world > 1 and totaln and pairs:
         # junction rows sharded over the ranks (distributed.pairwise_sharded); every rank formats its own
         # rows, rank 0 stitches the parts into the one output table
         from . import distributed
         try:
             row_ptr, col = exclusion_csr(events, clusters)
             out = distributed.pairwise_sharded(ctx, L.comm(ctx), np.ascontiguousarray(counts, dtype=np.int32), row_ptr, col,
-                                               args.multiple_test_correction)
+                                               args.multiple_test_correction, test="chi2" if args.chi2 else "fisher")
         finally:
             if own_ctx:
                 ctx.close()
@@ -159,7 +159,7 @@ def run_with(args, ctx=None):
     if not L.root:
         if own_ctx:
             ctx.close()
-        return                       # (--chi2 and empty inputs are not sharded: rank 0 alone)
+        return                       # (empty inputs are not sharded: rank 0 alone)
     if totaln and pairs and hasattr(ctx, "fisher_pairs_dev"):
         try:
             row_ptr, col = exclusion_csr(events, clusters)

@@ -22,6 +22,19 @@ class OracleEngine:
     def fisher_pairs(self, incl, excl):
         return O.fisher_pairs(incl, excl)
 
+    def chi2_pairs(self, incl, excl):
+        """-> (p, number of tables with a zero expected frequency), the shape of engine.Context.chi2_pairs"""
+        n, s = incl.shape
+        pairs = O.pair_list(s)
+        out, bad = np.ones((n, len(pairs))), 0
+        for r in range(n):
+            for q, (i, j) in enumerate(pairs):
+                try:
+                    out[r, q] = O.chi2_yates_restated(incl[r, i], incl[r, j], excl[r, i], excl[r, j])
+                except ValueError:
+                    bad += 1
+        return out, bad
+
     def bh_columns(self, p):
         return O.bh_columns(p)
 
@@ -106,6 +119,16 @@ def _pairwise_problem():
     return counts, row_ptr, col
 
 
+def _chi2_problem():
+    """40 rows in overlapping pairs (2i <-> 2i + 1), 5 samples, counts >= 1: every 2x2 table has positive margins"""
+    n, s = 40, 5
+    rng = np.random.default_rng(77)
+    counts = rng.integers(1, 60, size=(n, s)).astype(np.int32)
+    row_ptr = np.arange(n + 1, dtype=np.int64)
+    col = (np.arange(n) ^ 1).astype(np.int32)
+    return counts, row_ptr, col
+
+
 def _pairwise_worker(rank, world, port, q):
     import torch.distributed as dist
     from splicedice_amd import distributed
@@ -122,6 +145,21 @@ def _pairwise_worker(rank, world, port, q):
         for mode in ("pairwise", "none", "all"):
             out = distributed.pairwise_sharded(OracleEngine(), distributed.GlooComm(), mine, row_ptr, col, mode)
             res[mode] = (out["own"], out["p"])
+        # --chi2 on shards of its own small problem (rows in overlapping pairs: no empty row or column anywhere) ...
+        c2, rp2, col2 = _chi2_problem()
+        part2 = shard.shard_plan(rp2, col2, world)[rank]
+        mine2 = c2[part2["ext_lo"]:part2["ext_hi"]].copy()
+        out = distributed.pairwise_sharded(OracleEngine(), distributed.GlooComm(), mine2, rp2, col2, "pairwise", test="chi2")
+        res["chi2"] = (out["own"], out["p"])
+        # ... and the abort: ONE table with a zero expected frequency, in the LAST rank's rows, stops every rank
+        if rank == world - 1:
+            mine2[part2["own_hi"] - part2["ext_lo"] - 1, :2] = 0
+            mine2[part2["own_hi"] - part2["ext_lo"] - 2, :2] = 0
+        try:
+            distributed.pairwise_sharded(OracleEngine(), distributed.GlooComm(), mine2, rp2, col2, "none", test="chi2")
+            res["chi2_abort"] = "no error"
+        except ValueError as e:
+            res["chi2_abort"] = str(e)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -154,11 +192,17 @@ def test_sharded_pairwise_column_bh_equals_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    c2, rp2, col2 = _chi2_problem()
+    _, excl2 = O.calculate_psi_vectorised(c2, rp2, col2)
+    p2, bad2 = OracleEngine().chi2_pairs(c2, excl2)
+    assert bad2 == 0
+    want["chi2"] = O.bh_columns(p2)
     covered = 0
     for rank, res in results:
-        for mode in ("pairwise", "none", "all"):
+        for mode in ("pairwise", "none", "all", "chi2"):
             (lo, hi), got = res[mode]
             assert np.array_equal(got, want[mode][lo:hi]), (rank, mode)
+        assert res["chi2_abort"].startswith(distributed.CHI2_ZERO_MSG), (rank, res["chi2_abort"])
         covered += res["none"][0][1] - res["none"][0][0]
     assert covered == counts.shape[0]
     assert distributed.pair_column_ranges(15, 4) == [(0, 3), (3, 7), (7, 11), (11, 15)]

@@ -40,10 +40,16 @@ def test_sharded_pipeline_on_engine_matches_oracle(ctx):
         a, b = part["own_lo"] - part["ext_lo"], part["own_hi"] - part["ext_lo"]
         full = O.calculate_psi_vectorised(counts, row_ptr, col)[0]
         assert np.array_equal(loc[a:b], full[part["own_lo"]:part["own_hi"]], equal_nan=True)
-        # and the device-resident shard statistics (PS -> quantise -> rank-sum without leaving HBM)
-        st = distributed.shard_stats(ctx, np.ascontiguousarray(counts[part["ext_lo"]:part["ext_hi"]]), rp, cl, a, b - a,
-                                     g1, g2)
-        st = {k_: v.to_host() for k_, v in st.items()}
+        # and the device-resident shard object (PS -> quantise -> rank-sum into ONE packed block without leaving HBM)
+        sh = distributed.CompareShard(ctx, distributed.SingleComm(), counts.shape[0], counts.shape[1], [part], g1, g2)
+        try:
+            sh.load(np.ascontiguousarray(counts[part["ext_lo"]:part["ext_hi"]]), rp, cl)
+            sh.step()
+            ctx.sync()
+            st = sh.result()
+        finally:
+            sh.free()
+        assert all(v.shape[0] == b - a for v in st.values())
         sl = slice(part["own_lo"], part["own_hi"])
         tt = want["tested"][sl].astype(bool)
         assert np.array_equal(st["tested"], want["tested"][sl]) and np.array_equal(st["z"][tt], want["z"][sl][tt])
