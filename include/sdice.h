@@ -121,6 +121,18 @@ int sdice_ps_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const
 int sdice_ps_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
                      const int64_t* d_row_ptr, const int32_t* d_col, double* d_ps);
 
+/* ---- exclusion sums of a float64 count table: `pairwise` on fractional counts.  pairwise_fisher.py:46-61 parses the
+ *      table with dtype=float and :158-160 adds the rows named in the event's cluster, np.sum(counts[mask], axis=0):
+ *      one IEEE addition per row in TABLE order; scipy.stats.fisher_exact then truncates the float sums (and the
+ *      float inclusion counts) to int64.  Same shapes as sdice_ps_f64; excl[n_out,s] float64 =
+ *      counts[col[k0]] + counts[col[k0+1]] + ... left to right (0.0 for an empty list).  The caller lists the rows of
+ *      every event in ascending (table) order and truncates.
+ */
+int sdice_excl_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* counts,
+                   const int64_t* row_ptr, const int32_t* col, double* excl);
+int sdice_excl_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
+                       const int64_t* d_row_ptr, const int32_t* d_col, double* d_excl);
+
 /* --lowCoverageNan (SPLICEDICE.py:307-309): ps[low_idx[i]] = NaN, flat indices r*s+c */
 int sdice_mark_low(sdice_ctx* ctx, int64_t n_elems, float* ps, const int64_t* low_idx,
                    int64_t n_low);

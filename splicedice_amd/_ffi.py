@@ -41,6 +41,8 @@ SIGNATURES = {
     "sdice_ps_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
     "sdice_ps_f64": [ctxp, C.c_int64, C.c_int64, C.c_int32, vp, vp, vp, vp],
     "sdice_ps_f64_dev": [ctxp, C.c_int64, C.c_int64, C.c_int32, vp, vp, vp, vp],
+    "sdice_excl_f64": [ctxp, C.c_int64, C.c_int64, C.c_int32, vp, vp, vp, vp],
+    "sdice_excl_f64_dev": [ctxp, C.c_int64, C.c_int64, C.c_int32, vp, vp, vp, vp],
     "sdice_mark_low": [ctxp, C.c_int64, vp, vp, C.c_int64],
     "sdice_mark_low_dev": [ctxp, C.c_int64, vp, vp, C.c_int64],
     "sdice_quantize3": [ctxp, C.c_int64, vp],

@@ -6,12 +6,16 @@
 #include <algorithm>
 #include <cstdint>
 #include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 void sdice_set_error(const char* fmt, ...);
 
 namespace {
+// An exception inside a worker (or std::system_error from a thread that cannot be started) must not reach
+// std::terminate: workers catch into `err`, every started thread is joined, and the first exception is rethrown on
+// the caller's thread, where the extern "C" function-try-block turns it into SDICE_ERR_*.
 template <class F>
 void for_blocks(int64_t n, int threads, F f) {
     int used = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
@@ -19,12 +23,24 @@ void for_blocks(int64_t n, int threads, F f) {
     if (used > 64) used = 64;
     if (n < 4096) used = 1;
     std::vector<std::thread> pool;
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto guarded = [&](int64_t a, int64_t b) {
+        try { f(a, b); }
+        catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+    };
     const int64_t per = (n + used - 1) / used;
-    for (int t = 0; t < used; ++t) {
-        const int64_t a = std::min<int64_t>(n, t * per), b = std::min<int64_t>(n, a + per);
-        if (a < b) pool.emplace_back(f, a, b);
+    try {
+        for (int t = 0; t < used; ++t) {
+            const int64_t a = std::min<int64_t>(n, t * per), b = std::min<int64_t>(n, a + per);
+            if (a < b) pool.emplace_back(guarded, a, b);
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!err) err = std::current_exception();
     }
     for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
 }
 }  // namespace
 

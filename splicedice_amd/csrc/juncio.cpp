@@ -42,6 +42,15 @@ struct sdice_juncfile {
 };
 
 namespace {
+// joins every started thread when the scope ends, also when std::thread's constructor threw half way through the pool
+// (the workers themselves do not allocate and cannot throw)
+struct JoinAll {
+    std::vector<std::thread>& pool;
+    ~JoinAll() { for (auto& t : pool) if (t.joinable()) t.join(); }
+};
+}  // namespace
+
+namespace {
 
 struct Field { const char* a; const char* b; };
 
@@ -274,8 +283,8 @@ extern "C" int sdice_junc_read(sdice_juncfile* t, int32_t min_length, int32_t ma
         work(0, 0, t->n);
     } else {
         std::vector<std::thread> pool;
+        JoinAll joiner{pool};          // (a thread that cannot be started throws: the started ones are joined first)
         for (int k = 0; k < nthreads; ++k) pool.emplace_back(work, k, t->n * k / nthreads, t->n * (k + 1) / nthreads);
-        for (auto& th : pool) th.join();
     }
     int64_t first_bad = -1;
     for (auto b : bad)
@@ -326,8 +335,8 @@ extern "C" int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const
         work(0, n_q);
     } else {
         std::vector<std::thread> pool;
+        JoinAll joiner{pool};
         for (int k = 0; k < nthreads; ++k) pool.emplace_back(work, n_q * k / nthreads, n_q * (k + 1) / nthreads);
-        for (auto& th : pool) th.join();
     }
     return SDICE_OK;
 } catch (const std::exception& e) {

@@ -19,6 +19,10 @@ namespace {
 
 constexpr int PF_WAVES = 4;
 
+// EXCL: store the sum of the listed rows alone (additions in list order, starting from the first row) instead of
+// own / (own + sum): `pairwise` on a fractional count table (np.sum(counts[rows], axis=0), pairwise_fisher.py:158-160,
+// adds the rows in table order; fisher_exact then truncates the float sums to int64)
+template <bool EXCL>
 __global__ void __launch_bounds__(PF_WAVES * 64) ps_f64_kernel(int64_t n_out, int s, const double* __restrict__ counts,
                                                                 const int64_t* __restrict__ row_ptr,
                                                                 const int32_t* __restrict__ col, double* __restrict__ ps) {
@@ -29,9 +33,10 @@ __global__ void __launch_bounds__(PF_WAVES * 64) ps_f64_kernel(int64_t n_out, in
         const int64_t k0 = row_ptr[row], k1 = row_ptr[row + 1];
         const double* own_row = counts + row * s;
         for (int j = lane; j < s; j += 64) {
-            const double own = own_row[j];
+            const double own = EXCL ? 0.0 : own_row[j];
             double acc = own;
             int64_t k = k0;
+            if (EXCL && k < k1) { acc = counts[(int64_t)col[k] * s + j]; ++k; }
             for (; k + 4 <= k1; k += 4) {          // four neighbour rows in flight, added in list order
                 const double a0 = counts[(int64_t)col[k] * s + j];
                 const double a1 = counts[(int64_t)col[k + 1] * s + j];
@@ -40,15 +45,15 @@ __global__ void __launch_bounds__(PF_WAVES * 64) ps_f64_kernel(int64_t n_out, in
                 acc += a0; acc += a1; acc += a2; acc += a3;
             }
             for (; k < k1; ++k) acc += counts[(int64_t)col[k] * s + j];
-            ps[row * s + j] = own / acc;
+            ps[row * s + j] = EXCL ? acc : own / acc;
         }
     }
 }
 
 }  // namespace
 
-extern "C" int sdice_ps_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
-                                const int64_t* d_row_ptr, const int32_t* d_col, double* d_ps) {
+static int ps_f64_dev(sdice_ctx* ctx, bool excl, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
+                      const int64_t* d_row_ptr, const int32_t* d_col, double* d_ps) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n_out >= 0 && n_rows >= n_out && s >= 0, "need 0 <= n_out <= n_rows, s >= 0");
     if (n_out == 0 || s == 0) return SDICE_OK;
@@ -56,13 +61,25 @@ extern "C" int sdice_ps_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, i
     SD_HIP(hipSetDevice(ctx->device));
     const int64_t blocks = sd_ceil_div(n_out, PF_WAVES);
     const unsigned grid = (unsigned)(blocks < 256 * 64 ? blocks : 256 * 64);
-    SD_LAUNCH(ctx, "ps_f64_kernel", ps_f64_kernel, dim3(grid), dim3(PF_WAVES * 64), 0, n_out, (int)s, d_counts, d_row_ptr,
-              d_col, d_ps);
+    if (excl) SD_LAUNCH(ctx, "ps_f64_kernel", (ps_f64_kernel<true>), dim3(grid), dim3(PF_WAVES * 64), 0, n_out, (int)s, d_counts,
+                        d_row_ptr, d_col, d_ps);
+    else SD_LAUNCH(ctx, "ps_f64_kernel", (ps_f64_kernel<false>), dim3(grid), dim3(PF_WAVES * 64), 0, n_out, (int)s, d_counts,
+                   d_row_ptr, d_col, d_ps);
     return SDICE_OK;
 }
 
-extern "C" int sdice_ps_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* counts,
-                            const int64_t* row_ptr, const int32_t* col, double* ps) {
+extern "C" int sdice_ps_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
+                                const int64_t* d_row_ptr, const int32_t* d_col, double* d_ps) {
+    return ps_f64_dev(ctx, false, n_out, n_rows, s, d_counts, d_row_ptr, d_col, d_ps);
+}
+
+extern "C" int sdice_excl_f64_dev(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* d_counts,
+                                  const int64_t* d_row_ptr, const int32_t* d_col, double* d_excl) {
+    return ps_f64_dev(ctx, true, n_out, n_rows, s, d_counts, d_row_ptr, d_col, d_excl);
+}
+
+static int ps_f64_host(sdice_ctx* ctx, bool excl, int64_t n_out, int64_t n_rows, int32_t s, const double* counts,
+                       const int64_t* row_ptr, const int32_t* col, double* ps) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n_out >= 0 && n_rows >= n_out && s >= 0, "need 0 <= n_out <= n_rows, s >= 0");
     if (n_out == 0 || s == 0) return SDICE_OK;
@@ -101,7 +118,7 @@ extern "C" int sdice_ps_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32
     SD_STEP(hipMemcpyAsync(d_counts, counts, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     SD_STEP(hipMemcpyAsync(d_rp, row_ptr, (size_t)(n_out + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (nnz > 0) SD_STEP(hipMemcpyAsync(d_col, col, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream));
-    rc = sdice_ps_f64_dev(ctx, n_out, n_rows, s, d_counts, d_rp, d_col, d_ps);
+    rc = ps_f64_dev(ctx, excl, n_out, n_rows, s, d_counts, d_rp, d_col, d_ps);
     if (rc == SDICE_OK) {
         SD_STEP(hipMemcpyAsync(ps, d_ps, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         SD_STEP(hipStreamSynchronize(ctx->stream));
@@ -109,4 +126,14 @@ extern "C" int sdice_ps_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32
 #undef SD_STEP
     cleanup();
     return rc;
+}
+
+extern "C" int sdice_ps_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* counts,
+                            const int64_t* row_ptr, const int32_t* col, double* ps) {
+    return ps_f64_host(ctx, false, n_out, n_rows, s, counts, row_ptr, col, ps);
+}
+
+extern "C" int sdice_excl_f64(sdice_ctx* ctx, int64_t n_out, int64_t n_rows, int32_t s, const double* counts,
+                              const int64_t* row_ptr, const int32_t* col, double* excl) {
+    return ps_f64_host(ctx, true, n_out, n_rows, s, counts, row_ptr, col, excl);
 }

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <fcntl.h>
@@ -115,6 +116,9 @@ inline void put_repr(std::string& out, T x) {
     }
 }
 
+// An exception inside a worker (std::bad_alloc from a growing row buffer) or from a thread that cannot be started
+// must not reach std::terminate: workers catch into `err`, every started thread is joined, the first exception is
+// rethrown on the caller's thread (the extern "C" function-try-blocks map it to SDICE_ERR_*).
 template <typename F>
 void parallel_rows(int64_t n, int threads, F&& fn) {
     if (threads < 1) threads = 1;
@@ -122,11 +126,22 @@ void parallel_rows(int64_t n, int threads, F&& fn) {
     if (n < 4096) threads = 1;
     if (threads == 1) { fn(0, 0, n); return; }
     std::vector<std::thread> pool;
-    for (int t = 0; t < threads; ++t) {
-        const int64_t a = n * t / threads, b = n * (t + 1) / threads;
-        pool.emplace_back([=, &fn] { fn(t, a, b); });
+    std::exception_ptr err;
+    std::mutex err_mu;
+    try {
+        for (int t = 0; t < threads; ++t) {
+            const int64_t a = n * t / threads, b = n * (t + 1) / threads;
+            pool.emplace_back([=, &fn, &err, &err_mu] {
+                try { fn(t, a, b); }
+                catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+            });
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!err) err = std::current_exception();
     }
     for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
 }
 
 }  // namespace

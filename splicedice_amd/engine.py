@@ -181,6 +181,18 @@ class Context:
               "sdice_ps_f64")
         return ps
 
+    def excl_f64(self, counts, row_ptr, col):
+        """-> float64[n,s]: for every row the sum of the listed rows of a float64 table, one addition per row in list
+        order (np.sum(counts[mask], axis=0) of pairwise_fisher.py:158-160 when the lists are in table order)"""
+        counts = _c(counts, np.float64)
+        n, s = counts.shape
+        row_ptr, col = _c(row_ptr, np.int64), _c(col, np.int32)
+        if row_ptr.size != n + 1:
+            raise ValueError("excl_f64: row_ptr must hold n + 1 entries")
+        out = np.empty((n, s), dtype=np.float64)
+        check(self.lib.sdice_excl_f64(self.h, n, n, s, _ptr(counts), _ptr(row_ptr), _ptr(col), _ptr(out)), "sdice_excl_f64")
+        return out
+
     def mark_low(self, ps, low_flat_idx):
         ps = _c(ps, np.float32)
         idx = _c(low_flat_idx, np.int64)

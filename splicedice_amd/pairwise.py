@@ -31,14 +31,40 @@ def get_clusters(filename):
 
 
 def get_event_counts(filename, filter_list=None):
-    """samples, events, int32 counts; `-f` keeps only listed rows (pairwise_fisher.py:46-61)."""
+    """samples, events, counts; `-f` keeps only listed rows (pairwise_fisher.py:46-61).  counts: int32 when every cell
+    is a non-negative integer (the usual `_inclusionCounts.tsv`), else the float64 table as parsed -- the reference
+    reads with dtype=float and fractional / normalised counts are legal there (see fractional_tables)."""
     header, events, mat = textio.read_table_numeric(filename, np.float64)
     samples = header.rstrip().split("\t")[1:]
     if filter_list is not None:
         keep = [i for i, e in enumerate(events) if e in filter_list]
         events = [events[i] for i in keep]
         mat = mat[keep] if keep else np.zeros((0, len(samples)))
-    return samples, events, textio.counts_to_int32(mat, filename)
+    try:
+        return samples, events, textio.counts_to_int32(mat, filename)
+    except ValueError:
+        return samples, events, np.ascontiguousarray(mat, dtype=np.float64)
+
+
+def fractional_tables(ctx, counts, row_ptr, col):
+    """`pairwise` on a table with non-integer cells, as the reference computes it: the exclusion counts are FLOAT sums
+    over the event's rows in table order (np.sum(counts[mask], axis=0), pairwise_fisher.py:158-160), and
+    scipy.stats.fisher_exact casts the 2x2 table to int64 -- truncation towards zero of the float inclusion count
+    and of the float SUM (not the sum of truncated counts).  -> (incl int32[n,s], excl int64[n,s]) for the Fisher kernel."""
+    n = counts.shape[0]
+    # every event's rows in ascending (table) order: the order of the additions shows in the last bit of a sum, and a
+    # sum that lands within an ulp of an integer truncates differently
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(row_ptr))
+    order = np.lexsort((col, rows))
+    excl_f = ctx.excl_f64(counts, row_ptr, np.ascontiguousarray(col[order], dtype=np.int32))
+    incl_t, excl_t = np.trunc(counts), np.trunc(excl_f)
+    if not (np.isfinite(incl_t).all() and np.isfinite(excl_t).all()):
+        raise ValueError("pairwise: the count table holds NaN or infinite cells")
+    if (incl_t < 0).any() or (excl_t < 0).any():
+        raise ValueError("All values in `table` must be nonnegative.")        # scipy.stats.fisher_exact's own words
+    if (incl_t >= 2.0 ** 31).any() or (excl_t >= 2.0 ** 62).any():
+        raise ValueError("pairwise: counts must stay below 2**31")
+    return incl_t.astype(np.int32), excl_t.astype(np.int64)
 
 
 def exclusion_csr(events, clusters):
@@ -59,7 +85,7 @@ def exclusion_csr(events, clusters):
 SLAB_BYTES = 256 << 20      # host memory of the streamed output (rows x pairs x 8 B per slab)
 
 
-def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header, path):
+def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header, path, excl=None):
     """exclusion sums -> per-pair test -> correction with the [n, pairs] p-value matrix RESIDENT IN HBM
     (config 4: 200 000 x 19 900 doubles = 32 GB; the reference holds it in host memory,
     pairwise_fisher.py:123-193), then streamed to the output table in row slabs: device -> host ->
@@ -69,8 +95,11 @@ def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header,
     d_counts = ctx.to_device(counts, np.int32)
     d_rp = ctx.to_device(row_ptr, np.int64)
     d_col = ctx.to_device(col if col.size else np.zeros(1, np.int32), np.int32)
-    d_excl = ctx.empty((n, s), np.int64)
-    ctx.ps_dev(d_counts, d_rp, d_col, d_excl, None)
+    if excl is None:
+        d_excl = ctx.empty((n, s), np.int64)
+        ctx.ps_dev(d_counts, d_rp, d_col, d_excl, None)
+    else:
+        d_excl = ctx.to_device(excl, np.int64)            # (fractional table: truncated float sums, fractional_tables)
     d_p = ctx.empty((n, pairs), np.float64)
     if chi2:
         d_bad = ctx.empty(1, np.int64)
@@ -140,6 +169,31 @@ def run_with(args, ctx=None):
     own_ctx = ctx is None
     ctx = ctx if ctx is not None else Context(L.local_rank)
     header = "clusterID\t" + "\t".join(columns) + "\n"
+    fractional = counts.dtype != np.int32
+    if fractional and args.chi2:
+        raise ValueError("pairwise --chi2 needs integer counts here (the chi-square kernel takes integer tables; the "
+                         "reference would feed the fractional table to scipy.stats.chi2_contingency as it stands)")
+    if fractional and totaln and pairs:
+        # a table with non-integer cells: float sums in table order, truncated as scipy's int64 cast does; one rank
+        if L.root:
+            try:
+                row_ptr, col = exclusion_csr(events, clusters)
+                incl, excl = fractional_tables(ctx, counts, row_ptr, col)
+                if hasattr(ctx, "fisher_pairs_dev"):
+                    device_pipeline(ctx, incl, row_ptr, col, False, args.multiple_test_correction, events, header, args.output, excl)
+                else:
+                    parray = ctx.fisher_pairs(incl, excl)
+                    if args.multiple_test_correction == "all":
+                        parray = ctx.bh(parray.ravel()).reshape(parray.shape)
+                    elif args.multiple_test_correction == "pairwise":
+                        parray = ctx.bh_columns(parray)
+                    textio.write_table(args.output, header, events, np.asarray(parray, dtype=np.float64), "repr")
+            finally:
+                if own_ctx:
+                    ctx.close()
+        elif own_ctx:
+            ctx.close()
+        return
     if L.world > 1 and totaln and pairs:
         # junction rows sharded over the ranks (distributed.pairwise_sharded); every rank formats its own
         # rows, rank 0 stitches the parts into the one output table
