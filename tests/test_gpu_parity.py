@@ -273,6 +273,44 @@ def test_ps_vs_oracle(ctx, n, s, seed):
     assert np.array_equal(only_excl, excl)
 
 
+@pytest.mark.parametrize("n,s", [(30000, 100), (20000, 500), (50000, 36), (9000, 1000), (40000, 8)])
+def test_ps_kernel_generations_agree(ctx, n, s):
+    """the three tile kernels behind sdice_ps_dev -- second-generation register-staged (ps.dma = 0, the default),
+    LDS-DMA (1), first generation (2) -- on the device path WITH the clustering's reach words (halo sized per tile),
+    without them (ps.use_reach = 0), with exclusion sums, and with the fused '.3f' store: bit-identical"""
+    cr, left, right, strand = synth.make_junctions(n, n + s)
+    d = [ctx.to_device(x) for x in (cr, left, right, strand)]
+    d_row_of, d_rp = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    d_col, nnz = ctx.cluster_dev(*d, d_row_of, d_rp)
+    counts = synth.make_counts(n, s, n + s + 1)
+    counts[7, :] = (1 << 24) - 1                       # one tile whose bound forces the 64-bit path
+    d_counts = ctx.to_device(counts)
+    d_ps, d_excl = ctx.empty((n, s), np.float32), ctx.empty((n, s), np.int64)
+    refs = {}
+    try:
+        for kern, reach, q3 in ((2, 1, 0), (0, 1, 0), (0, 0, 0), (1, 1, 0), (1, 0, 0), (2, 1, 1), (0, 1, 1), (1, 1, 1)):
+            ctx.set_param("ps.dma", kern)
+            ctx.set_param("ps.use_reach", reach)
+            ctx.set_param("ps.quantize3", q3)
+            d_ps.memset(0xff)
+            d_excl.memset(0xff)
+            ctx.ps_dev(d_counts, d_rp, d_col, d_excl, d_ps)
+            ctx.sync()
+            got = (d_ps.to_host().view(np.uint32), d_excl.to_host())
+            if q3 not in refs:
+                refs[q3] = got
+            assert np.array_equal(got[0], refs[q3][0]) and np.array_equal(got[1], refs[q3][1]), (kern, reach, q3)
+    finally:
+        ctx.set_param("ps.dma", 0)
+        ctx.set_param("ps.use_reach", 1)
+        ctx.set_param("ps.quantize3", 0)
+    ref = refs[0]
+    row_ptr, col = d_rp.to_host(), d_col.to_host()
+    want_ps, want_excl = O.calculate_psi_vectorised(counts[:3000], row_ptr[:3001], np.minimum(col[: int(row_ptr[3000])], 2999))
+    inside = np.array([(col[row_ptr[r]:row_ptr[r + 1]] < 3000).all() for r in range(3000)])
+    assert np.array_equal(ref[1][:3000][inside], want_excl[inside])
+
+
 @pytest.mark.parametrize("lds,threads,tile_rows,halo", [(8192, 64, 0, -1), (32768, 256, 7, 0), (65536, 1024, 0, 3),
                                                          (163840, 512, 0, 40), (81920, 1024, 0, 1)])
 def test_ps_launch_shapes(ctx, lds, threads, tile_rows, halo):
