@@ -571,8 +571,9 @@ __device__ __forceinline__ uint64_t bhv_key(const BhvArgs& a, int64_t i) {
     return present ? key_of(v) : BHV_ABSENT;
 }
 __device__ __forceinline__ int64_t bhv_sample_pos(const BhvArgs& a, int j) {
-    const int64_t lo = (int64_t)j * a.n / a.S, hi = (int64_t)(j + 1) * a.n / a.S;
-    return lo + (int64_t)(hash32((unsigned)j * 2654435761u + 12345u) % (unsigned)(hi - lo));
+    // jittered regular sample: one position in every stride of n / S values (32-bit arithmetic: n <= 2 Mi)
+    const unsigned stride = (unsigned)(a.n / a.S);
+    return (int64_t)((unsigned)j * stride + hash32((unsigned)j * 2654435761u + 12345u) % stride);
 }
 
 __global__ void __launch_bounds__(256) bhv_rank_kernel(BhvArgs a) {
@@ -600,8 +601,8 @@ __global__ void __launch_bounds__(256) bhv_rank_kernel(BhvArgs a) {
 __device__ __forceinline__ void bhv_load_splitters(const BhvArgs& a, uint64_t* sk, uint32_t* si, int tid) {
     for (int s = tid; s < a.S; s += BHV_T) {
         const unsigned r = a.rank[s];
-        if (r != 0u && r % (unsigned)a.spb == 0u) {
-            const int b = (int)(r / (unsigned)a.spb) - 1;
+        if (r != 0u && (r & (unsigned)(a.spb - 1)) == 0u) {              // (spb is a power of two)
+            const int b = (int)(r >> (31 - __builtin_clz((unsigned)a.spb))) - 1;
             if (b < a.B - 1) { const int64_t pos = bhv_sample_pos(a, s); sk[b] = bhv_key(a, pos); si[b] = (uint32_t)pos; }
         }
     }
