@@ -13,7 +13,7 @@
 //   3. scan:     bucket starts per segment (buckets are contiguous rank ranges);
 //   4. scatter:  same search again, one global atomic per (tile, bucket) reserves a run, 12-byte
 //                (key, index) elements land in their bucket;
-//   5. buckets:  ONE WAVE per bucket (mean ~160 values, up to 1024): bitonic network on registers
+//   5. buckets:  ONE WAVE per bucket (mean ~200 values, up to 1024): bitonic network on registers
 //                (4/8/16 keys per lane, cross-lane steps by ds_bpermute, no LDS storage, no
 //                barriers), ranks = bucket start + position, p*m/rank exactly as the generic path
 //                computes it, suffix minimum inside the bucket, scattered to [segment][index] with
@@ -954,7 +954,9 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     a.segs = (int)segs;
     int B = 1;
     if (m > 1024) {
-        int64_t mean = std::max<int64_t>(ctx->param("bh.mean", 160), sd_ceil_div(m, (int64_t)MAX_B));
+        // (mean bucket size, same process, 25 000 x 19 900: 96 -> 29.1 ms, 128 -> 23.6, 160 -> 23.3, 200 -> 22.0, 224 -> 28.2,
+        //  256 -> 35.4: per-bucket overhead below, the 8 / 16-keys-per-lane kernel for buckets beyond 256 values above)
+        int64_t mean = std::max<int64_t>(ctx->param("bh.mean", 200), sd_ceil_div(m, (int64_t)MAX_B));
         B = (int)sd_ceil_div(m, mean);
         if (B > MAX_B) B = MAX_B;
     }
