@@ -16,7 +16,20 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
-for wl in ("quant", "compare", "pairwise", "e2e", "quant2m500"):
+def src_sha16(files):
+    """as bench.kernel_source_sha16: the profile is only quoted for the kernel source it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in files:
+        with open(os.path.join(root, "splicedice_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+KERNEL_SOURCES = {"quant": ["ps.hip"], "compare": ["ranksum.hip"], "pairwise": ["fisher.hip"], "e2e": ["ranksum.hip"]}
+
+for wl in ("quant", "quantc2", "compare", "pairwise", "e2e"):
     files = newest(os.path.join(src, f"{wl}_trace", "*", "*_kernel_stats.csv"))
     if not files:
         continue
@@ -35,8 +48,8 @@ for wl in ("quant", "compare", "pairwise", "e2e", "quant2m500"):
 # HBM traffic of every kernel from the two PMC passes.  MI355X_MICROARCH.md (HBM section): both
 # counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream
 # (x2), WRITE_SIZE is exact.
-DOMINANT = [("quant", "quant", "ps_tile_kernel", 1000000, 100), ("compare", "compare", "ranksum_pair", 1000000, 100),
-            ("pairwise", "pairwise", "fisher_pairs_kernel", 25000, 200), ("quant2m500", "quant", "ps_tile_kernel", 2000000, 500),
+DOMINANT = [("quant", "quant", "ps_tile", 2000000, 500), ("quantc2", "quant", "ps_tile", 1000000, 100),
+            ("compare", "compare", "ranksum_pair", 1000000, 100), ("pairwise", "pairwise", "fisher_pairs_kernel", 25000, 200),
             ("e2e", "e2e", "ranksum_count_kernel", 625000, 1000)]
 records = []
 for wl, wl_key, dom, n, s in DOMINANT:
@@ -63,29 +76,31 @@ for wl, wl_key, dom, n, s in DOMINANT:
     if hit:
         records.append({"workload": wl_key, "n": n, "s": s, "kernel": [k for k in traffic if k.startswith(dom)][0],
                         "hbm_bytes_per_launch": (2 * hit[0].get("FETCH_SIZE", 0) + hit[0].get("WRITE_SIZE", 0)) * 1024,
+                        "src_sha16": src_sha16(KERNEL_SOURCES[wl_key]),
                         "source": f"profiles/{tag}_{wl}_pmc.csv (FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE)"})
 if records:
     json.dump(records, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-# SQ counters of the quant chain (one pass per counter), per kernel and launch
-sq = collections.defaultdict(dict)
-for d in sorted(glob.glob(os.path.join(src, "quant_sq_*"))):
-    cname = os.path.basename(d)[len("quant_sq_"):]
-    files = newest(os.path.join(d, "*", "*_counter_collection.csv"))
-    if not files:
-        continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if r["Counter_Name"] == cname:
-            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        sq[k][cname] = sum(v) / len(v)
-if sq:
-    names = sorted({c for v in sq.values() for c in v})
-    with open(os.path.join(dst, f"{tag}_quant_sq_counters.csv"), "w", newline="") as fh:
-        out = csv.writer(fh)
-        out.writerow(["kernel"] + [f"{c}_per_launch" for c in names])
-        for k in sorted(sq):
-            out.writerow([k] + [f"{sq[k].get(c, float('nan')):.0f}" for c in names])
+# SQ counters (one pass per counter), per workload, kernel and launch
+for wl in ("quant", "quantc2", "compare", "e2e"):
+    sq = collections.defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(src, f"{wl}_sq_*"))):
+        cname = os.path.basename(d)[len(f"{wl}_sq_"):]
+        files = newest(os.path.join(d, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            if r["Counter_Name"] == cname:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            sq[k][cname] = sum(v) / len(v)
+    if sq:
+        names = sorted({c for v in sq.values() for c in v})
+        with open(os.path.join(dst, f"{tag}_{wl}_sq_counters.csv"), "w", newline="") as fh:
+            out = csv.writer(fh)
+            out.writerow(["kernel"] + [f"{c}_per_launch" for c in names])
+            for k in sorted(sq):
+                out.writerow([k] + [f"{sq[k].get(c, float('nan')):.0f}" for c in names])
 # VALU issue of the Fisher kernel (f64-VALU bound): instructions and active lanes per launch
 pw = {}
 for cname in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"):
@@ -101,5 +116,6 @@ if len(pw) == 2:
     pw["n"], pw["s"] = 25000, 200
     pw["active_lanes_of_64"] = pw["SQ_THREAD_CYCLES_VALU_per_launch"] / pw["SQ_INSTS_VALU_per_launch"]
     pw["source"] = f"rocprofv3 --pmc passes of `bench.py --workload pairwise` ({tag}), one counter per run"
+    pw["src_sha16"] = src_sha16(KERNEL_SOURCES["pairwise"])
     json.dump(pw, open(os.path.join(dst, "pairwise_valu.json"), "w"), indent=1)
 print("profiles written:", sorted(os.listdir(dst)))
