@@ -169,6 +169,10 @@ int sdice_fisher_pairs(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* incl
                        const int64_t* excl, double* p);
 int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t* d_incl,
                            const int64_t* d_excl, double* d_p);
+/* measurement aid (no reference counterpart): with the context parameter "fisher.count_steps" = 1 the pair kernel
+ * counts the lane-steps it issues and those that advanced a live walk inside its support; this returns the two
+ * counts of the last sdice_fisher_pairs[_dev] call (bench.py: roofline.valu_f64.useful_lane_frac). */
+int sdice_fisher_step_stats(sdice_ctx* ctx, uint64_t* useful, uint64_t* issued);
 /* m independent 2x2 tables abcd[m,4] int64 -> p[m] (same kernel math; KAT entry point) */
 int sdice_fisher_tables(sdice_ctx* ctx, int64_t m, const int64_t* abcd, double* p);
 

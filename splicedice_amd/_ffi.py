@@ -52,6 +52,7 @@ SIGNATURES = {
     "sdice_fisher_pairs": [ctxp, C.c_int64, C.c_int32, vp, vp, vp],
     "sdice_fisher_pairs_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp],
     "sdice_fisher_tables": [ctxp, C.c_int64, vp, vp],
+    "sdice_fisher_step_stats": [ctxp, vp, vp],
     "sdice_chi2_pairs": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, c_i64p],
     "sdice_chi2_pairs_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp],
     "sdice_bh": [ctxp, C.c_int64, vp, vp],

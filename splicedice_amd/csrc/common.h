@@ -83,6 +83,7 @@ struct sdice_ctx {
     // log-factorial table of the Fisher kernel: lf[k] = lgamma(k+1)
     double* d_lf = nullptr;
     int64_t lf_n = 0;
+    uint64_t fisher_steps[2] = {0, 0};   // fisher.count_steps: useful / issued lane-steps of the last launch
 
     // profiling
     bool prof_on = false;

@@ -323,6 +323,12 @@ class Context:
         n, s = d_incl.shape
         check(self.lib.sdice_fisher_pairs_dev(self.h, n, s, d_incl.ptr, d_excl.ptr, d_p.ptr), "sdice_fisher_pairs_dev")
 
+    def fisher_step_stats(self):
+        """(useful, issued) lane-steps of the last Fisher launch made with fisher.count_steps = 1"""
+        u, t = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.sdice_fisher_step_stats(self.h, C.byref(u), C.byref(t)), "sdice_fisher_step_stats")
+        return int(u.value), int(t.value)
+
     def chi2_pairs_dev(self, d_incl, d_excl, d_p, d_n_bad):
         n, s = d_incl.shape
         check(self.lib.sdice_chi2_pairs_dev(self.h, n, s, d_incl.ptr, d_excl.ptr, d_p.ptr, d_n_bad.ptr), "sdice_chi2_pairs_dev")

@@ -7,7 +7,7 @@ from splicedice_amd import synth
 from splicedice_amd.engine import Context
 n, s = int(sys.argv[1]), int(sys.argv[2])
 cfgs = sys.argv[3:] or [""]
-DEFAULTS = {"fisher.refill": 16, "fisher.unroll": 8}
+DEFAULTS = {"fisher.refill": 16, "fisher.unroll": 8, "fisher.count_steps": 0}
 ctx = Context(0)
 junc = synth.make_junctions(n, 4)
 counts_in = synth.make_counts(n, s, 40)
@@ -27,10 +27,14 @@ for rep in range(2):
         ms = []
         for it in range(3):
             ctx.sync(); ctx.timer_start(); ctx.fisher_pairs_dev(d_counts, d_excl, d_p); ms.append(ctx.timer_stop())
+        extra = ""
+        if any(k == "fisher.count_steps" and int(v) for k, v in kv):
+            u, t = ctx.fisher_step_stats()
+            extra = f"  useful lane-steps {u:.3e} of {t:.3e} issued = {u / max(t, 1):.3f}; {u / (n * pairs):.1f} per pair"
         for k, v in kv:
             ctx.set_param(k, DEFAULTS[k])
         got = d_p.offset(0, (4, pairs)).to_host()
         if ref is None:
             ref = got
         err = np.max(np.abs(got - ref) / ref)
-        print(f"rep {rep} [{c}] {min(ms[1:]):.3f} ms  ({n * pairs / min(ms[1:]) / 1e6:.2f} G p/s)  max rel diff to first config {err:.1e}", flush=True)
+        print(f"rep {rep} [{c}] {min(ms[1:]):.3f} ms  ({n * pairs / min(ms[1:]) / 1e6:.2f} G p/s)  max rel diff to first config {err:.1e}{extra}", flush=True)
