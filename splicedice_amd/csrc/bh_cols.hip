@@ -720,16 +720,19 @@ __device__ uint64_t bhv_sub_in_lds(uint64_t* ks, uint32_t* is, int n_s, int64_t 
     return carry;
 }
 
-__global__ void __launch_bounds__(BHV_T) bhv_bucket_kernel(BhvArgs a) {
+// LDS per value: key (8) + index (4) + sub-bucket (1) -- ONE copy of the bucket: a thread reads its values from HBM into
+// registers, scatters them into sub-bucket order, and after the ranking holds the finished (p m / rank, index, position)
+// in registers across a barrier before it overwrites the same arrays in sorted order.  5632 values = 73 KB, so that TWO
+// workgroups share a CU and all ~490 buckets of 1 M values are resident at once (with two copies, 150 KB, the
+// workgroups ran in two rounds: 99 us, half of it waiting).
+constexpr int BHV_EPT = 6;            // values per thread of a bucket workgroup (cap <= 6144)
+__global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
     extern __shared__ uint64_t smem_b[];
-    // LDS: K[cap] I[cap] K2[cap] I2[cap] SB[cap] + small tables
-    uint64_t* K1 = smem_b;
-    uint64_t* K2 = K1 + a.cap;
-    uint32_t* I1 = reinterpret_cast<uint32_t*>(K2 + a.cap);
-    uint32_t* I2 = I1 + a.cap;
+    uint64_t* K2 = smem_b;
+    uint32_t* I2 = reinterpret_cast<uint32_t*>(K2 + a.cap);
     uint8_t* SB = reinterpret_cast<uint8_t*>(I2 + a.cap);
-    __shared__ uint64_t ssk[64], smin[64];
-    __shared__ uint32_t ssi[64];
+    __shared__ uint64_t samK[256], ssk[64], smin[64];
+    __shared__ uint32_t samI[256], ssi[64];
     __shared__ unsigned scount[64], sstart[65], srank[256];
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -759,30 +762,39 @@ __global__ void __launch_bounds__(BHV_T) bhv_bucket_kernel(BhvArgs a) {
         }
         return;
     }
-    for (int i = tid; i < n_b; i += BHV_T) { K1[i] = a.keyS[start + i]; I1[i] = a.idxS[start + i]; }
+    uint64_t key[BHV_EPT];
+    uint32_t idx[BHV_EPT];
+#pragma unroll
+    for (int q = 0; q < BHV_EPT; ++q) {
+        const int i = tid + q * BHV_T;
+        key[q] = 0; idx[q] = 0;
+        if (i < n_b) { key[q] = a.keyS[start + i]; idx[q] = a.idxS[start + i]; }
+    }
     // sub-buckets of ~32..64 values: a power of two, at most 64
     int nsb = 1;
     while (nsb < 64 && nsb * 40 < n_b) nsb <<= 1;
-    __syncthreads();
     if (nsb > 1) {
-        // 4 * nsb regular samples (<= 256), ranked by counting (one sample per lane of the first waves, the others as
-        // broadcast reads); the sample of rank 4 (b + 1) is splitter b
+        // 4 * nsb regular samples (<= 256), ranked by counting: thread t counts, for sample t mod ns, the smaller samples
+        // among slice t / ns of the sample; the sample of rank 4 (b + 1) is splitter b
         const int ns = 4 * nsb;
         const int nsh = 31 - __builtin_clz((unsigned)ns);            // ns is a power of two; j * n_b < 2^21
-        // all threads: thread t counts, for sample t mod ns, the smaller samples among slice t / ns of the sample
+        if (tid < ns) {
+            const int pos = (tid * n_b) >> nsh;
+            samK[tid] = a.keyS[start + pos]; samI[tid] = a.idxS[start + pos];
+        }
+        __syncthreads();
         const int slices = BHV_T / ns;                                // >= 4
         const int per = ns / slices;                                  // samples per slice (a power of two >= 1)
         {
             const int sm = tid & (ns - 1), sl = tid >> nsh;
-            const int pos = (sm * n_b) >> nsh;
-            const uint64_t km = K1[pos];
-            const uint32_t im = I1[pos];
+            const uint64_t km = samK[sm];
+            const uint32_t im = samI[sm];
             unsigned c = 0;
             for (int j0 = sl * per; j0 < (sl + 1) * per; j0 += 8) {
                 uint64_t kj[8];
                 uint32_t ij[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int pj = (min(j0 + u, ns - 1) * n_b) >> nsh; kj[u] = K1[pj]; ij[u] = I1[pj]; }
+                for (int u = 0; u < 8; ++u) { const int pj = min(j0 + u, ns - 1); kj[u] = samK[pj]; ij[u] = samI[pj]; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) c += (j0 + u < (sl + 1) * per && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
             }
@@ -791,83 +803,90 @@ __global__ void __launch_bounds__(BHV_T) bhv_bucket_kernel(BhvArgs a) {
         __syncthreads();
         if (tid < ns) {
             const unsigned c = srank[tid];
-            if (c != 0u && (c & 3u) == 0u) {
-                const int pos = (tid * n_b) >> nsh;
-                ssk[(c >> 2) - 1] = K1[pos]; ssi[(c >> 2) - 1] = I1[pos];
-            }
+            if (c != 0u && (c & 3u) == 0u) { ssk[(c >> 2) - 1] = samK[tid]; ssi[(c >> 2) - 1] = samI[tid]; }
         }
         __syncthreads();
     }
-    // classify (each thread up to cap / BHV_T values), count, scatter inside LDS
-    constexpr int EPT = 8;
-    int sub[EPT];
-    unsigned off[EPT];
+    // classify, count, scatter into sub-bucket order
+    {
+        int sub[BHV_EPT];
+        unsigned off[BHV_EPT];
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int i = tid + q * BHV_T;
-        sub[q] = -1;
-        if (i < n_b) {
-            sub[q] = nsb > 1 ? find_bucket(ssk, ssi, nsb - 1, K1[i], I1[i]) : 0;
-            off[q] = atomicAdd(&scount[sub[q]], 1u);
+        for (int q = 0; q < BHV_EPT; ++q) {
+            const int i = tid + q * BHV_T;
+            sub[q] = -1;
+            if (i < n_b) {
+                sub[q] = nsb > 1 ? find_bucket(ssk, ssi, nsb - 1, key[q], idx[q]) : 0;
+                off[q] = atomicAdd(&scount[sub[q]], 1u);
+            }
         }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const unsigned c = lane < nsb ? scount[lane] : 0u;
-        unsigned x = c;
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned c = lane < nsb ? scount[lane] : 0u;
+            unsigned x = c;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
-        sstart[lane] = x - c;
-        if (lane == 63) sstart[64] = x;
-    }
-    __syncthreads();
+            for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+            sstart[lane] = x - c;
+            if (lane == 63) sstart[64] = x;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int i = tid + q * BHV_T;
-        if (sub[q] >= 0) {
-            const unsigned d = sstart[sub[q]] + off[q];
-            K2[d] = K1[i]; I2[d] = I1[i]; SB[d] = (uint8_t)sub[q];
+        for (int q = 0; q < BHV_EPT; ++q) {
+            if (sub[q] >= 0) {
+                const unsigned d = sstart[sub[q]] + off[q];
+                K2[d] = key[q]; I2[d] = idx[q]; SB[d] = (uint8_t)sub[q];
+            }
         }
     }
     __syncthreads();
     // every thread ranks its own values inside their sub-bucket by COUNTING the smaller ones (composite (key, index)
-    // order; eight LDS reads in flight per trip; neighbouring threads share a sub-bucket, so the reads are near-broadcasts)
-    // and writes p * m / rank to the sorted position: values to K1, indices to I1 (free since the scatter).
+    // order; eight LDS reads in flight per trip; neighbouring threads share a sub-bucket, so the reads are near-broadcasts).
     // (A register sorting network per sub-bucket cost ~1.4 ds_bpermute per value and stage on the LDS crossbar; one wave
     //  per sub-bucket left most of the workgroup idle behind chains of LDS round trips.)
+    {
+        uint64_t ok[BHV_EPT];
+        uint32_t oi[BHV_EPT];
+        int op[BHV_EPT];
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int d = tid + q * BHV_T;
-        if (d < n_b) {
-            const int sb = SB[d];
-            const int s0 = (int)sstart[sb], n_s = (int)scount[sb];
-            const uint64_t km = K2[d];
-            const uint32_t im = I2[d];
-            unsigned c = 0;
-            for (int j0 = 0; j0 < n_s; j0 += 8) {
-                uint64_t kj[8];
-                uint32_t ij[8];
+        for (int q = 0; q < BHV_EPT; ++q) {
+            const int d = tid + q * BHV_T;
+            op[q] = -1; ok[q] = 0; oi[q] = 0;
+            if (d < n_b) {
+                const int sb = SB[d];
+                const int s0 = (int)sstart[sb], n_s = (int)scount[sb];
+                const uint64_t km = K2[d];
+                const uint32_t im = I2[d];
+                unsigned c = 0;
+                for (int j0 = 0; j0 < n_s; j0 += 8) {
+                    uint64_t kj[8];
+                    uint32_t ij[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = s0 + min(j0 + u, n_s - 1); kj[u] = K2[j]; ij[u] = I2[j]; }
+                    for (int u = 0; u < 8; ++u) { const int j = s0 + min(j0 + u, n_s - 1); kj[u] = K2[j]; ij[u] = I2[j]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    c += (j0 + u < n_s && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
+                    for (int u = 0; u < 8; ++u)
+                        c += (j0 + u < n_s && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
+                }
+                const int pos = s0 + (int)c;
+                const int64_t rank1 = (int64_t)start + pos + 1;
+                ok[q] = rank1 <= m_eff ? raw_bits(km, rank1, m_eff) : 0x7ff0000000000000ull;     // absent entries: +inf
+                oi[q] = im;
+                op[q] = pos;
             }
-            const int pos = s0 + (int)c;
-            const int64_t rank1 = (int64_t)start + pos + 1;
-            K1[pos] = rank1 <= m_eff ? raw_bits(km, rank1, m_eff) : 0x7ff0000000000000ull;     // absent entries: +inf
-            I1[pos] = im;
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BHV_EPT; ++q)
+            if (op[q] >= 0) { K2[op[q]] = ok[q]; I2[op[q]] = oi[q]; }
     }
     __syncthreads();
     // suffix minimum over the bucket's sorted positions: thread t owns positions [t * EPT, t * EPT + EPT)
     {
-        uint64_t v[EPT];
+        uint64_t v[BHV_EPT];
         uint64_t run = ~0ull;
 #pragma unroll
-        for (int k = EPT - 1; k >= 0; --k) {
-            const int pos = tid * EPT + k;
-            const uint64_t r = pos < n_b ? K1[pos] : ~0ull;
+        for (int k = BHV_EPT - 1; k >= 0; --k) {
+            const int pos = tid * BHV_EPT + k;
+            const uint64_t r = pos < n_b ? K2[pos] : ~0ull;
             run = r < run ? r : run;
             v[k] = run;
         }
@@ -886,10 +905,10 @@ __global__ void __launch_bounds__(BHV_T) bhv_bucket_kernel(BhvArgs a) {
         ex = ex < later ? ex : later;
         if (tid == 0) a.bmin[b] = x < later ? x : later;
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const int pos = tid * EPT + k;
+        for (int k = 0; k < BHV_EPT; ++k) {
+            const int pos = tid * BHV_EPT + k;
             if (pos < n_b) {
-                const uint32_t dst = I1[pos];
+                const uint32_t dst = I2[pos];
                 a.qpart[dst] = v[k] < ex ? v[k] : ex;
                 a.bid[dst] = (uint16_t)b;
             }
@@ -1042,8 +1061,8 @@ int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const 
     Arena& A = ctx->arena;
     BhvArgs a;
     a.p = d_p; a.tested = d_tested; a.masked = masked ? 1 : 0; a.n = n; a.q = d_q;
-    // buckets of ~2048 values, 16 samples per bucket: a bucket beyond the LDS capacity (6016 = 2.9 x the mean) has a
-    // probability of ~1e-9 (it would be sorted in HBM by one wave)
+    // buckets of ~2048 values, 16 samples per bucket (sizes ~ Gamma(16): sigma = mean / 4): a bucket beyond the LDS
+    // capacity (5632 = mean + 7 sigma) practically never occurs (it would be sorted in HBM by one wave)
     int64_t mean = ctx->param("bhv.mean", 2048);
     if (mean < 512) mean = 512;
     if (mean < sd_ceil_div(n, (int64_t)1024)) mean = sd_ceil_div(n, (int64_t)1024);
@@ -1053,7 +1072,9 @@ int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const 
     a.B = B;
     a.spb = 16;
     a.S = a.spb * B;
-    a.cap = 6016;                                   // 6016 x 25 B = 150.4 KB of LDS
+    a.cap = (int)ctx->param("bhv.cap", 5632);       // 5632 x 13 B = 73 KB of LDS: two bucket workgroups per CU
+    if (a.cap < 64) a.cap = 64;
+    if (a.cap > BHV_T * BHV_EPT) a.cap = BHV_T * BHV_EPT;
     const size_t N = (size_t)n;
     // one zeroed block: rank[S] | gcount[B] | cursor[B] | m_eff
     const size_t zwords = (size_t)a.S + 2 * (size_t)B + 4;
@@ -1075,7 +1096,7 @@ int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const 
     const size_t lds_t = (size_t)B * 20;
     SD_LAUNCH(ctx, "bhv_count_kernel", (bhv_tile_kernel<false>), dim3(tiles), dim3(BHV_T), lds_t, a);
     SD_LAUNCH(ctx, "bhv_scatter_kernel", (bhv_tile_kernel<true>), dim3(tiles), dim3(BHV_T), lds_t, a);
-    const size_t lds_b = (size_t)a.cap * 25;
+    const size_t lds_b = (((size_t)a.cap * 13 + 15) / 16) * 16;
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bhv_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     SD_LAUNCH(ctx, "bhv_bucket_kernel", bhv_bucket_kernel, dim3((unsigned)B), dim3(BHV_T), lds_b, a);
     SD_LAUNCH(ctx, "bhv_finish_kernel", bhv_finish_kernel, dim3(tiles), dim3(BHV_T), 0, a);

@@ -921,8 +921,16 @@ def test_bh_vector_samplesort_vs_radix(ctx, n):
             ctx.bh_masked_dev(d_p, None, d_q)
             out[path] = d_q.to_host()
         assert np.array_equal(out[1].view(np.uint64), out[2].view(np.uint64))
+        if n <= 100_000:
+            # buckets beyond the LDS capacity of a bucket workgroup (forced: every bucket) take the in-HBM network
+            ctx.set_param("bh.vector_path", 2)
+            ctx.set_param("bhv.cap", 512)
+            d_p, d_q = ctx.to_device(pm), ctx.empty(n, np.float64)
+            ctx.bh_masked_dev(d_p, None, d_q)
+            assert np.array_equal(out[1].view(np.uint64), d_q.to_host().view(np.uint64))
     finally:
         ctx.set_param("bh.vector_path", 0)
+        ctx.set_param("bhv.cap", 5632)
 
 
 def test_bh_high_word_runs(ctx):
