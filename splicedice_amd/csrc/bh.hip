@@ -22,7 +22,7 @@ size_t sd_bh_cols_scratch(int64_t m, int64_t segs);
 bool sd_bh_cols_supported(int64_t m, int64_t segs);
 int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_cm, double* d_out, int64_t out_pitch);
 bool sd_bh_vector_supported(int64_t n);
-size_t sd_bh_vector_scratch(int64_t n);
+size_t sd_bh_vector_scratch(sdice_ctx* ctx, int64_t n);
 int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, bool masked, double* d_q);
 
 namespace {
@@ -252,10 +252,10 @@ extern "C" int sdice_bh_dev(sdice_ctx* ctx, int64_t m, const double* d_p, double
     if (m == 0) return SDICE_OK;
     SD_ARG(d_p && d_q, "NULL pointer");
     SD_HIP(hipSetDevice(ctx->device));
-    // bh.vector_path: 0 = by size, 1 = radix path, 2 = sample-sort path (bh_cols.hip, five launches)
+    // bh.vector_path: 0 = by size, 1 = radix path, 2 = sample-sort path (bh_cols.hip, four launches)
     const int64_t vpath = ctx->param("bh.vector_path", 0);
     if (vpath != 1 && sd_bh_vector_supported(m)) {
-        SD_TRY(ctx->arena.reserve(sd_bh_vector_scratch(m), ctx->stream));
+        SD_TRY(ctx->arena.reserve(sd_bh_vector_scratch(ctx, m), ctx->stream));
         return sd_bh_vector_samplesort(ctx, m, d_p, nullptr, false, d_q);
     }
     SD_ARG(vpath != 2, "bh.vector_path = 2 needs 16384 <= m <= 2 Mi values");
@@ -271,7 +271,7 @@ extern "C" int sdice_bh_masked_dev(sdice_ctx* ctx, int64_t n, const double* d_p,
     SD_HIP(hipSetDevice(ctx->device));
     const int64_t vpath = ctx->param("bh.vector_path", 0);
     if (vpath != 1 && sd_bh_vector_supported(n)) {
-        SD_TRY(ctx->arena.reserve(sd_bh_vector_scratch(n), ctx->stream));
+        SD_TRY(ctx->arena.reserve(sd_bh_vector_scratch(ctx, n), ctx->stream));
         return sd_bh_vector_samplesort(ctx, n, d_p, d_tested, true, d_q);
     }
     SD_ARG(vpath != 2, "bh.vector_path = 2 needs 16384 <= n <= 2 Mi values");

@@ -530,18 +530,18 @@ __global__ void __launch_bounds__(256) bhs_finish_kernel(BhsArgs a, double* __re
 }
 
 // =====================================================================================================
-// ONE long vector (compare_sample_sets: 1 M p-values; `--multiple_test_correction all`): sample sort in five
-// launches instead of the 29 of the radix path (8 passes x 3 kernels + 5), which were pure launch latency
+// ONE long vector (compare_sample_sets: 1 M p-values; `--multiple_test_correction all`): sample sort in four
+// launches (+ one memset) instead of the 29 of the radix path (8 passes x 3 kernels + 5), which were pure launch latency
 // (0.26 ms for 16 MB of algorithmic traffic):
-//   bhv_rank     ranks of a jittered regular sample (8 per bucket) by brute force over the grid;
-//   bhv_count    every 8th ranked sample is a splitter; tile of 4096 values, binary search in LDS, one global atomic
-//                per (tile, bucket); counts the present entries (masked variant);
-//   bhv_scatter  the same search, bucket starts from the counts (every workgroup scans them itself), 12-byte
-//                (key, index) elements land in their bucket;
-//   bhv_bucket   one WORKGROUP per bucket (~4096 values in LDS): a local sample sort into sub-buckets of ~64..128, one
-//                wave per sub-bucket sorts it in registers (wave_bitonic), rank = bucket start + position,
-//                p * m / rank with the generic path's arithmetic, suffix minima inside the sub-bucket and over the
-//                bucket's sub-buckets, partial results scattered to the original positions with the bucket id;
+//   bhv_rank     ranks of a jittered regular sample (16 per bucket) by brute force over the grid;
+//   bhv_scatter  every 16th ranked sample is a splitter; tile of 4096 values, binary search in LDS, one global atomic
+//                per (tile, bucket) reserves a run in the bucket's SLOT (2.75 x the mean bucket: no counting pass;
+//                an element that finds its slot full goes to an overflow list), 12-byte (key, index) elements;
+//                counts the present entries (masked variant);
+//   bhv_bucket   one WORKGROUP per bucket (~2048 values, one copy in LDS, two workgroups per CU): a local sample
+//                into sub-buckets of ~40, every thread ranks its values inside their sub-bucket by counting,
+//                rank = bucket start + position, p * m / rank with the generic path's arithmetic, suffix minima over
+//                the bucket, partial results scattered to the original positions with the bucket id;
 //   bhv_finish   suffix minima over the bucket minima (every workgroup for itself), min(own, later buckets, 1).
 // Ties are broken by index in every comparison (a vector of ONE repeated value still splits evenly); absent entries
 // (masked variant) carry the key ~0, sort behind every p-value and are counted out of m.  Bit-identical to the radix path.
@@ -550,10 +550,13 @@ struct BhvArgs {
     int64_t n;
     int B, spb, S;
     uint32_t* rank;        // [S]
-    unsigned* gcount;      // [B]
-    unsigned* cursor;      // [B]
+    unsigned* cursor;      // [B] fill of the slots = bucket sizes
     unsigned long long* m_eff;
-    uint64_t* keyS; uint32_t* idxS;     // [n] bucketed
+    uint64_t* keyS; uint32_t* idxS;     // [B][cap] the buckets' slots
+    unsigned long long* ovf_n;          // elements that found their slot full (adversarial input only) ...
+    uint64_t* ovfK; uint32_t* ovfI; uint16_t* ovfB;     // [n] ... with their bucket
+    unsigned long long* spill_n;        // [n] where the slow path puts such a bucket together
+    uint64_t* spillK; uint32_t* spillI;
     uint64_t* qpart;       // [n]
     uint16_t* bid;         // [n]
     uint64_t* bmin;        // [B]
@@ -620,8 +623,10 @@ __device__ __forceinline__ unsigned bhv_block_excl_scan(unsigned v, unsigned* ws
     return pre;
 }
 
-template <bool SCATTER>
-__global__ void __launch_bounds__(BHV_T) bhv_tile_kernel(BhvArgs a) {
+// classify a tile against the splitters and move it straight into the buckets' SLOTS of `cap` elements each -- no
+// counting pass in front: a slot is 2.75 x the mean bucket, and the (practically impossible) elements beyond it go to
+// an overflow list that the bucket's slow path collects.  cursor[b] ends as the size of bucket b.
+__global__ void __launch_bounds__(BHV_T) bhv_scatter_kernel(BhvArgs a) {
     extern __shared__ uint64_t smem_v[];
     uint64_t* sk = smem_v;                                            // [B]
     uint32_t* si = reinterpret_cast<uint32_t*>(sk + a.B);             // [B]
@@ -652,32 +657,30 @@ __global__ void __launch_bounds__(BHV_T) bhv_tile_kernel(BhvArgs a) {
             off[q] = atomicAdd(&hist[bkt[q]], 1u);
         }
     }
-    __syncthreads();
-    if (!SCATTER) {
-        for (int b = tid; b < a.B; b += BHV_T)
-            if (hist[b]) atomicAdd(&a.gcount[b], hist[b]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) present += (unsigned)__shfl_xor((int)present, o);
-        if ((tid & 63) == 0) wsum[tid >> 6] = present;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned tot = 0;
-            for (int w = 0; w < BHV_T / 64; ++w) tot += wsum[w];
-            if (tot) atomicAdd(a.m_eff, (unsigned long long)tot);
-        }
-        return;
+    for (int o = 32; o > 0; o >>= 1) present += (unsigned)__shfl_xor((int)present, o);
+    if ((tid & 63) == 0) wsum[tid >> 6] = present;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < BHV_T / 64; ++w) tot += wsum[w];
+        if (tot) atomicAdd(a.m_eff, (unsigned long long)tot);
     }
-    // bucket starts from the global counts (B <= 1024: one counter per thread), then this tile's run in each bucket
-    const unsigned gc = tid < a.B ? a.gcount[tid] : 0u;
-    const unsigned start = bhv_block_excl_scan(gc, wsum, tid);
-    if (tid < a.B) base[tid] = start + (hist[tid] ? atomicAdd(&a.cursor[tid], hist[tid]) : 0u);
+    if (tid < a.B) base[tid] = hist[tid] ? atomicAdd(&a.cursor[tid], hist[tid]) : 0u;      // (B <= 1024: one bucket per thread)
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < BHV_E; ++q) {
         if (bkt[q] >= 0) {
-            const int64_t dst = (int64_t)base[bkt[q]] + off[q];
-            a.keyS[dst] = key[q];
-            a.idxS[dst] = (uint32_t)(e0 + q * BHV_T + tid);
+            const unsigned d = base[bkt[q]] + off[q];
+            const uint32_t idx = (uint32_t)(e0 + q * BHV_T + tid);
+            if (d < (unsigned)a.cap) {
+                const int64_t dst = (int64_t)bkt[q] * a.cap + d;
+                a.keyS[dst] = key[q];
+                a.idxS[dst] = idx;
+            } else {
+                const unsigned long long o = atomicAdd(a.ovf_n, 1ull);
+                a.ovfK[o] = key[q]; a.ovfI[o] = idx; a.ovfB[o] = (uint16_t)bkt[q];
+            }
         }
     }
 }
@@ -738,8 +741,8 @@ __global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int64_t m_eff = (int64_t)*a.m_eff;
-    // bucket start = sum of the counts before it
-    const unsigned gc = tid < a.B ? a.gcount[tid] : 0u;
+    // bucket start = sum of the sizes before it
+    const unsigned gc = tid < a.B ? a.cursor[tid] : 0u;
     unsigned before = tid < b ? gc : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) before += (unsigned)__shfl_xor((int)before, o);
@@ -749,12 +752,29 @@ __global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
     __syncthreads();
     unsigned start = 0;
     for (int w = 0; w < BHV_T / 64; ++w) start += wsum[w];
-    const int n_b = (int)a.gcount[b];
+    const int n_b = (int)a.cursor[b];
+    const uint64_t* slotK = a.keyS + (int64_t)b * a.cap;
+    const uint32_t* slotI = a.idxS + (int64_t)b * a.cap;
     if (n_b == 0) { if (tid == 0) a.bmin[b] = ~0ull; return; }
     if (n_b > a.cap) {
-        // (adversarial input only) the bucket does not fit LDS: its first wave sorts it in place in HBM
+        // (adversarial input only) the bucket does not fit its slot, let alone LDS: its first wave puts it together --
+        // the slot and the bucket's entries of the overflow list -- and sorts it in place in HBM
         if (wave == 0) {
-            uint64_t* ks = a.keyS + start; uint32_t* is = a.idxS + start;
+            unsigned long long so = 0;
+            if (lane == 0) so = atomicAdd(a.spill_n, (unsigned long long)n_b);
+            so = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(so >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)(so & 0xffffffffu), 0);
+            uint64_t* ks = a.spillK + so; uint32_t* is = a.spillI + so;
+            for (int p = lane; p < a.cap; p += 64) { ks[p] = slotK[p]; is[p] = slotI[p]; }
+            const long long n_o = (long long)*a.ovf_n;
+            int fill = a.cap;
+            for (long long t0 = 0; t0 < n_o; t0 += 64) {
+                const long long t = t0 + lane;
+                const bool mine = t < n_o && a.ovfB[t] == (uint16_t)b;
+                const unsigned long long mm = __ballot(mine);
+                if (mine) { const int d = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u)); ks[d] = a.ovfK[t]; is[d] = a.ovfI[t]; }
+                fill += __popcll(mm);
+            }
+            __threadfence_block();
             const uint64_t mn = bhv_sub_in_lds(ks, is, n_b, (int64_t)start, m_eff, lane);
             __threadfence();
             for (int p = lane; p < n_b; p += 64) { a.qpart[is[p]] = ks[p]; a.bid[is[p]] = (uint16_t)b; }
@@ -768,7 +788,7 @@ __global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
     for (int q = 0; q < BHV_EPT; ++q) {
         const int i = tid + q * BHV_T;
         key[q] = 0; idx[q] = 0;
-        if (i < n_b) { key[q] = a.keyS[start + i]; idx[q] = a.idxS[start + i]; }
+        if (i < n_b) { key[q] = slotK[i]; idx[q] = slotI[i]; }
     }
     // sub-buckets of ~32..64 values: a power of two, at most 64
     int nsb = 1;
@@ -780,7 +800,7 @@ __global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
         const int nsh = 31 - __builtin_clz((unsigned)ns);            // ns is a power of two; j * n_b < 2^21
         if (tid < ns) {
             const int pos = (tid * n_b) >> nsh;
-            samK[tid] = a.keyS[start + pos]; samI[tid] = a.idxS[start + pos];
+            samK[tid] = slotK[pos]; samI[tid] = slotI[pos];
         }
         __syncthreads();
         const int slices = BHV_T / ns;                                // >= 4
@@ -1055,47 +1075,64 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
 // One vector of n p-values (masked: entries with tested == 0 -- or p < 0 without a mask -- are absent).  Supported sizes:
 // the sample fits the brute-force ranking and a bucket fits LDS.
 bool sd_bh_vector_supported(int64_t n) { return n >= 16384 && n <= ((int64_t)2 << 20); }      // (up to 1024 buckets of 2048 on average)
-size_t sd_bh_vector_scratch(int64_t n) { return (size_t)n * 30 + (1 << 16); }
-
-int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, bool masked, double* d_q) {
-    Arena& A = ctx->arena;
-    BhvArgs a;
-    a.p = d_p; a.tested = d_tested; a.masked = masked ? 1 : 0; a.n = n; a.q = d_q;
-    // buckets of ~2048 values, 16 samples per bucket (sizes ~ Gamma(16): sigma = mean / 4): a bucket beyond the LDS
-    // capacity (5632 = mean + 7 sigma) practically never occurs (it would be sorted in HBM by one wave)
+// geometry of the one-vector path: buckets of ~2048 values, 16 samples per bucket (sizes ~ Gamma(16): sigma = mean / 4);
+// a bucket beyond its slot / the LDS capacity (5632 = mean + 7 sigma) practically never occurs (slow path: one wave, HBM)
+static void bhv_geometry(sdice_ctx* ctx, int64_t n, int* B_out, int* cap_out) {
     int64_t mean = ctx->param("bhv.mean", 2048);
     if (mean < 512) mean = 512;
     if (mean < sd_ceil_div(n, (int64_t)1024)) mean = sd_ceil_div(n, (int64_t)1024);
     int B = (int)sd_ceil_div(n, mean);
     if (B < 2) B = 2;
     if (B > 1024) B = 1024;
+    int cap = (int)ctx->param("bhv.cap", 5632);     // 5632 x 13 B = 73 KB of LDS: two bucket workgroups per CU
+    if (cap < 64) cap = 64;
+    if (cap > BHV_T * BHV_EPT) cap = BHV_T * BHV_EPT;
+    *B_out = B; *cap_out = cap;
+}
+// slots (12 B x cap per bucket) + partial results (10 B per value) + the overflow list and the slow path's assembly area
+// (14 + 12 B per value) + the sample ranks
+size_t sd_bh_vector_scratch(sdice_ctx* ctx, int64_t n) {
+    int B, cap;
+    bhv_geometry(ctx, n, &B, &cap);
+    return (size_t)n * 36 + (size_t)B * (size_t)cap * 12 + (size_t)B * 80 + (1 << 16);
+}
+
+int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, bool masked, double* d_q) {
+    Arena& A = ctx->arena;
+    BhvArgs a;
+    a.p = d_p; a.tested = d_tested; a.masked = masked ? 1 : 0; a.n = n; a.q = d_q;
+    int B;
+    bhv_geometry(ctx, n, &B, &a.cap);
     a.B = B;
     a.spb = 16;
     a.S = a.spb * B;
-    a.cap = (int)ctx->param("bhv.cap", 5632);       // 5632 x 13 B = 73 KB of LDS: two bucket workgroups per CU
-    if (a.cap < 64) a.cap = 64;
-    if (a.cap > BHV_T * BHV_EPT) a.cap = BHV_T * BHV_EPT;
     const size_t N = (size_t)n;
-    // one zeroed block: rank[S] | gcount[B] | cursor[B] | m_eff
-    const size_t zwords = (size_t)a.S + 2 * (size_t)B + 4;
+    // one zeroed block: rank[S] | cursor[B] | m_eff | ovf_n | spill_n
+    const size_t zwords = (size_t)a.S + (size_t)B + 8;
     unsigned* z = (unsigned*)A.alloc(zwords * 4);
-    a.keyS = (uint64_t*)A.alloc(N * 8);
+    a.keyS = (uint64_t*)A.alloc((size_t)B * a.cap * 8);
     a.qpart = (uint64_t*)A.alloc(N * 8);
+    a.ovfK = (uint64_t*)A.alloc(N * 8);
+    a.spillK = (uint64_t*)A.alloc(N * 8);
     a.bmin = (uint64_t*)A.alloc((size_t)B * 8);
-    a.idxS = (uint32_t*)A.alloc(N * 4);
+    a.idxS = (uint32_t*)A.alloc((size_t)B * a.cap * 4);
+    a.ovfI = (uint32_t*)A.alloc(N * 4);
+    a.spillI = (uint32_t*)A.alloc(N * 4);
     a.bid = (uint16_t*)A.alloc(N * 2);
-    if (!z || !a.keyS || !a.qpart || !a.bmin || !a.idxS || !a.bid) return SDICE_ERR_NOMEM;
+    a.ovfB = (uint16_t*)A.alloc(N * 2);
+    if (!z || !a.keyS || !a.qpart || !a.ovfK || !a.spillK || !a.bmin || !a.idxS || !a.ovfI || !a.spillI || !a.bid || !a.ovfB)
+        return SDICE_ERR_NOMEM;
     a.rank = z;
-    a.gcount = z + a.S;
-    a.cursor = a.gcount + B;
-    a.m_eff = (unsigned long long*)(a.cursor + B + ((a.S + 2 * B) & 1));      // 8-byte aligned
+    a.cursor = z + a.S;
+    a.m_eff = (unsigned long long*)(a.cursor + B + ((a.S + B) & 1));      // 8-byte aligned
+    a.ovf_n = a.m_eff + 1;
+    a.spill_n = a.m_eff + 2;
     SD_HIP(hipMemsetAsync(z, 0, zwords * 4, ctx->stream));
     const unsigned gs = (unsigned)sd_ceil_div(a.S, 256);
     SD_LAUNCH(ctx, "bhv_rank_kernel", bhv_rank_kernel, dim3(gs, gs), dim3(256), 0, a);
     const unsigned tiles = (unsigned)sd_ceil_div(n, (int64_t)(BHV_T * BHV_E));
     const size_t lds_t = (size_t)B * 20;
-    SD_LAUNCH(ctx, "bhv_count_kernel", (bhv_tile_kernel<false>), dim3(tiles), dim3(BHV_T), lds_t, a);
-    SD_LAUNCH(ctx, "bhv_scatter_kernel", (bhv_tile_kernel<true>), dim3(tiles), dim3(BHV_T), lds_t, a);
+    SD_LAUNCH(ctx, "bhv_scatter_kernel", bhv_scatter_kernel, dim3(tiles), dim3(BHV_T), lds_t, a);
     const size_t lds_b = (((size_t)a.cap * 13 + 15) / 16) * 16;
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bhv_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     SD_LAUNCH(ctx, "bhv_bucket_kernel", bhv_bucket_kernel, dim3((unsigned)B), dim3(BHV_T), lds_b, a);
