@@ -67,6 +67,20 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
     return x;
 }
 
+// c += (ka, ia) < (kb, ib) in composite order: the borrow of the 96-bit subtraction, added with carry -- four VALU
+// instructions (the compiler turns "ka < kb || (ka == kb && ia < ib)", and __builtin_subc chains too, into five compares
+// and their mask arithmetic)
+__device__ __forceinline__ void count_less96(unsigned& c, uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+    unsigned t;
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\t"
+        "v_subb_co_u32 %0, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %0, vcc, %6, %7, vcc\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(t), "+v"(c)
+        : "v"(ia), "v"(ib), "v"((unsigned)ka), "v"((unsigned)kb), "v"((unsigned)(ka >> 32)), "v"((unsigned)(kb >> 32))
+        : "vcc");
+}
+
 // number of splitters <= (k, i) in composite order
 __device__ __forceinline__ int find_bucket(const uint64_t* sk, const uint32_t* si, int ns, uint64_t k, uint32_t i) {
     int lo = 0, hi = ns;
@@ -729,7 +743,7 @@ __device__ uint64_t bhv_sub_in_lds(uint64_t* ks, uint32_t* is, int n_s, int64_t 
 // workgroups share a CU and all ~490 buckets of 1 M values are resident at once (with two copies, 150 KB, the
 // workgroups ran in two rounds: 99 us, half of it waiting).
 constexpr int BHV_EPT = 6;            // values per thread of a bucket workgroup (cap <= 6144)
-__global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
+__global__ void __launch_bounds__(BHV_T, 8) bhv_bucket_kernel(BhvArgs a) {
     extern __shared__ uint64_t smem_b[];
     uint64_t* K2 = smem_b;
     uint32_t* I2 = reinterpret_cast<uint32_t*>(K2 + a.cap);
@@ -816,7 +830,10 @@ __global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int pj = min(j0 + u, ns - 1); kj[u] = samK[pj]; ij[u] = samI[pj]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) c += (j0 + u < (sl + 1) * per && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = j0 + u < (sl + 1) * per;
+                    count_less96(c, in ? kj[u] : ~0ull, in ? ij[u] : ~0u, km, im);
+                }
             }
             if (c) atomicAdd(&srank[sm], c);
         }
@@ -877,14 +894,26 @@ __global__ void __launch_bounds__(BHV_T, 2) bhv_bucket_kernel(BhvArgs a) {
                 const uint64_t km = K2[d];
                 const uint32_t im = I2[d];
                 unsigned c = 0;
-                for (int j0 = 0; j0 < n_s; j0 += 8) {
+                int j0 = 0;
+                for (; j0 + 8 <= n_s; j0 += 8) {              // whole trips: eight reads in flight, no bound checks
                     uint64_t kj[8];
                     uint32_t ij[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const int j = s0 + min(j0 + u, n_s - 1); kj[u] = K2[j]; ij[u] = I2[j]; }
+                    for (int u = 0; u < 8; ++u) { kj[u] = K2[s0 + j0 + u]; ij[u] = I2[s0 + j0 + u]; }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        c += (j0 + u < n_s && (kj[u] < km || (kj[u] == km && ij[u] < im))) ? 1u : 0u;
+                    for (int u = 0; u < 8; ++u) count_less96(c, kj[u], ij[u], km, im);
+                }
+                if (j0 < n_s) {
+                    uint64_t kj[8];
+                    uint32_t ij[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {             // (beyond the sub-bucket: a key above every key)
+                        const bool in = j0 + u < n_s;
+                        const int j = s0 + min(j0 + u, n_s - 1);
+                        kj[u] = in ? K2[j] : ~0ull; ij[u] = in ? I2[j] : ~0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) count_less96(c, kj[u], ij[u], km, im);
                 }
                 const int pos = s0 + (int)c;
                 const int64_t rank1 = (int64_t)start + pos + 1;
