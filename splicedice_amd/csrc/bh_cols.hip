@@ -594,22 +594,27 @@ __device__ __forceinline__ int64_t bhv_sample_pos(const BhvArgs& a, int j) {
 }
 
 __global__ void __launch_bounds__(256) bhv_rank_kernel(BhvArgs a) {
-    __shared__ uint64_t jk[256];
-    __shared__ uint32_t ji[256];
+    __shared__ __align__(16) uint64_t jk[256];
+    __shared__ __align__(16) uint32_t ji[256];
     const int t = threadIdx.x;
     const int i = blockIdx.x * 256 + t, j = blockIdx.y * 256 + t;
     uint64_t ik = 0; uint32_t ii = 0;
     if (i < a.S) { const int64_t pos = bhv_sample_pos(a, i); ik = bhv_key(a, pos); ii = (uint32_t)pos; }
-    jk[t] = ~0ull; ji[t] = ~0u;
+    jk[t] = ~0ull; ji[t] = ~0u;                  // (beyond the sample: a key above every key, never counted)
     if (j < a.S) { const int64_t pos = bhv_sample_pos(a, j); jk[t] = bhv_key(a, pos); ji[t] = (uint32_t)pos; }
     __syncthreads();
     if (i >= a.S) return;
-    const int nj = min(256, a.S - (int)blockIdx.y * 256);
+    // four samples per trip: two 16-byte reads of keys and one of indices (broadcasts) for four compares
     unsigned cnt = 0;
-#pragma unroll 8
-    for (int q = 0; q < nj; ++q) {
-        const uint64_t k = jk[q];
-        cnt += (k < ik || (k == ik && ji[q] < ii)) ? 1u : 0u;
+#pragma unroll 4
+    for (int q = 0; q < 256; q += 4) {
+        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&jk[q]);
+        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&jk[q + 2]);
+        const uint4 i4 = *reinterpret_cast<const uint4*>(&ji[q]);
+        count_less96(cnt, k01.x, i4.x, ik, ii);
+        count_less96(cnt, k01.y, i4.y, ik, ii);
+        count_less96(cnt, k23.x, i4.z, ik, ii);
+        count_less96(cnt, k23.y, i4.w, ik, ii);
     }
     if (cnt) atomicAdd(&a.rank[i], cnt);
 }
@@ -648,20 +653,20 @@ __global__ void __launch_bounds__(BHV_T) bhv_scatter_kernel(BhvArgs a) {
     unsigned* base = hist + a.B;                                      // [B]
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x;
-    for (int b = tid; b < a.B; b += BHV_T) hist[b] = 0;
-    bhv_load_splitters(a, sk, si, tid);
-    __syncthreads();
     const int64_t e0 = (int64_t)blockIdx.x * (BHV_T * BHV_E);
     uint64_t key[BHV_E];
     int bkt[BHV_E];
     unsigned off[BHV_E];
     unsigned present = 0;
 #pragma unroll
-    for (int q = 0; q < BHV_E; ++q) {
+    for (int q = 0; q < BHV_E; ++q) {                 // (the tile's values travel while the splitters are put together)
         const int64_t e = e0 + q * BHV_T + tid;
         key[q] = e < a.n ? bhv_key(a, e) : 0;
         present += (e < a.n && key[q] != BHV_ABSENT) ? 1u : 0u;
     }
+    for (int b = tid; b < a.B; b += BHV_T) hist[b] = 0;
+    bhv_load_splitters(a, sk, si, tid);
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < BHV_E; ++q) {
         const int64_t e = e0 + q * BHV_T + tid;
