@@ -564,6 +564,8 @@ struct BhvArgs {
     int64_t n;
     int B, spb, S;
     uint32_t* rank;        // [S]
+    unsigned* tile_done;   // [ceil(S / 256)] j tiles finished per column of the ranking grid
+    uint64_t* spl_k; uint32_t* spl_i;   // [B] splitters
     unsigned* cursor;      // [B] fill of the slots = bucket sizes
     unsigned long long* m_eff;
     uint64_t* keyS; uint32_t* idxS;     // [B][cap] the buckets' slots
@@ -603,31 +605,43 @@ __global__ void __launch_bounds__(256) bhv_rank_kernel(BhvArgs a) {
     jk[t] = ~0ull; ji[t] = ~0u;                  // (beyond the sample: a key above every key, never counted)
     if (j < a.S) { const int64_t pos = bhv_sample_pos(a, j); jk[t] = bhv_key(a, pos); ji[t] = (uint32_t)pos; }
     __syncthreads();
-    if (i >= a.S) return;
     // four samples per trip: two 16-byte reads of keys and one of indices (broadcasts) for four compares
     unsigned cnt = 0;
+    if (i < a.S) {
 #pragma unroll 4
-    for (int q = 0; q < 256; q += 4) {
-        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&jk[q]);
-        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&jk[q + 2]);
-        const uint4 i4 = *reinterpret_cast<const uint4*>(&ji[q]);
-        count_less96(cnt, k01.x, i4.x, ik, ii);
-        count_less96(cnt, k01.y, i4.y, ik, ii);
-        count_less96(cnt, k23.x, i4.z, ik, ii);
-        count_less96(cnt, k23.y, i4.w, ik, ii);
+        for (int q = 0; q < 256; q += 4) {
+            const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&jk[q]);
+            const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&jk[q + 2]);
+            const uint4 i4 = *reinterpret_cast<const uint4*>(&ji[q]);
+            count_less96(cnt, k01.x, i4.x, ik, ii);
+            count_less96(cnt, k01.y, i4.y, ik, ii);
+            count_less96(cnt, k23.x, i4.z, ik, ii);
+            count_less96(cnt, k23.y, i4.w, ik, ii);
+        }
+        if (cnt) atomicAdd(&a.rank[i], cnt);
     }
-    if (cnt) atomicAdd(&a.rank[i], cnt);
-}
-
-// splitters into LDS: sample s with rank r = spb * (b + 1) is splitter b
-__device__ __forceinline__ void bhv_load_splitters(const BhvArgs& a, uint64_t* sk, uint32_t* si, int tid) {
-    for (int s = tid; s < a.S; s += BHV_T) {
-        const unsigned r = a.rank[s];
-        if (r != 0u && (r & (unsigned)(a.spb - 1)) == 0u) {              // (spb is a power of two)
+    // the workgroup that completes a column of the grid (all j tiles of these 256 samples) reads the final ranks and
+    // writes the splitters: sample of rank spb * (b + 1) is splitter b -- the tile kernel then loads B - 1 finished
+    // splitters instead of walking the S ranks (eight dependent global round trips per workgroup)
+    // (no fence: the adds are device-scope atomics, performed at the memory side once vmcnt reaches zero, and the final
+    //  ranks are read back with an atomic as well -- a release fence here writes the L2 back and cost 50 us)
+    __shared__ unsigned last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) last = atomicAdd(&a.tile_done[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last && i < a.S) {
+        const unsigned r = atomicAdd(&a.rank[i], 0u);                     // (at the L2, where the other workgroups' adds landed)
+        if (r != 0u && (r & (unsigned)(a.spb - 1)) == 0u) {               // (spb is a power of two)
             const int b = (int)(r >> (31 - __builtin_clz((unsigned)a.spb))) - 1;
-            if (b < a.B - 1) { const int64_t pos = bhv_sample_pos(a, s); sk[b] = bhv_key(a, pos); si[b] = (uint32_t)pos; }
+            if (b < a.B - 1) { a.spl_k[b] = ik; a.spl_i[b] = ii; }
         }
     }
+}
+
+// splitters into LDS (written by the ranking kernel)
+__device__ __forceinline__ void bhv_load_splitters(const BhvArgs& a, uint64_t* sk, uint32_t* si, int tid) {
+    for (int b = tid; b < a.B - 1; b += BHV_T) { sk[b] = a.spl_k[b]; si[b] = a.spl_i[b]; }
 }
 // exclusive scan of up to 1024 counters held one per thread (BHV_T threads); returns this thread's prefix
 __device__ __forceinline__ unsigned bhv_block_excl_scan(unsigned v, unsigned* wsum /*[16]*/, int tid) {
@@ -748,32 +762,35 @@ __device__ uint64_t bhv_sub_in_lds(uint64_t* ks, uint32_t* is, int n_s, int64_t 
 // workgroups share a CU and all ~490 buckets of 1 M values are resident at once (with two copies, 150 KB, the
 // workgroups ran in two rounds: 99 us, half of it waiting).
 constexpr int BHV_EPT = 6;            // values per thread of a bucket workgroup (cap <= 6144)
+// sub-buckets: up to 128 of ~16 values, 2 samples each (sizes ~ Gamma(2): a value meets ~24 candidates on average; with
+// 64 sub-buckets of ~32 and 4 samples each -- Gamma(4) -- it met ~40, and the counting loop is the kernel's VALU load)
+constexpr int BHV_SPS_LOG = 1, BHV_SPS = 1 << BHV_SPS_LOG, BHV_NSB_MAX = 256 / BHV_SPS, BHV_SUB_MEAN = 20;
 __global__ void __launch_bounds__(BHV_T, 8) bhv_bucket_kernel(BhvArgs a) {
     extern __shared__ uint64_t smem_b[];
     uint64_t* K2 = smem_b;
     uint32_t* I2 = reinterpret_cast<uint32_t*>(K2 + a.cap);
     uint8_t* SB = reinterpret_cast<uint8_t*>(I2 + a.cap);
-    __shared__ uint64_t samK[256], ssk[64], smin[64];
-    __shared__ uint32_t samI[256], ssi[64];
-    __shared__ unsigned scount[64], sstart[65], srank[256];
+    __shared__ uint64_t samK[256], ssk[BHV_NSB_MAX], smin[16];
+    __shared__ uint32_t samI[256], ssi[BHV_NSB_MAX];
+    __shared__ unsigned scount[BHV_NSB_MAX], sstart[BHV_NSB_MAX + 1], srank[256];
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int64_t m_eff = (int64_t)*a.m_eff;
+    const uint64_t* slotK = a.keyS + (int64_t)b * a.cap;
+    const uint32_t* slotI = a.idxS + (int64_t)b * a.cap;
     // bucket start = sum of the sizes before it
     const unsigned gc = tid < a.B ? a.cursor[tid] : 0u;
     unsigned before = tid < b ? gc : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) before += (unsigned)__shfl_xor((int)before, o);
     if (lane == 0) wsum[wave] = before;
-    if (tid < 64) scount[tid] = 0;
+    if (tid < BHV_NSB_MAX) scount[tid] = 0;
     if (tid < 256) srank[tid] = 0;
     __syncthreads();
     unsigned start = 0;
     for (int w = 0; w < BHV_T / 64; ++w) start += wsum[w];
     const int n_b = (int)a.cursor[b];
-    const uint64_t* slotK = a.keyS + (int64_t)b * a.cap;
-    const uint32_t* slotI = a.idxS + (int64_t)b * a.cap;
     if (n_b == 0) { if (tid == 0) a.bmin[b] = ~0ull; return; }
     if (n_b > a.cap) {
         // (adversarial input only) the bucket does not fit its slot, let alone LDS: its first wave puts it together --
@@ -809,13 +826,13 @@ __global__ void __launch_bounds__(BHV_T, 8) bhv_bucket_kernel(BhvArgs a) {
         key[q] = 0; idx[q] = 0;
         if (i < n_b) { key[q] = slotK[i]; idx[q] = slotI[i]; }
     }
-    // sub-buckets of ~32..64 values: a power of two, at most 64
+    // sub-buckets: a power of two
     int nsb = 1;
-    while (nsb < 64 && nsb * 40 < n_b) nsb <<= 1;
+    while (nsb < BHV_NSB_MAX && nsb * BHV_SUB_MEAN < n_b) nsb <<= 1;
     if (nsb > 1) {
-        // 4 * nsb regular samples (<= 256), ranked by counting: thread t counts, for sample t mod ns, the smaller samples
-        // among slice t / ns of the sample; the sample of rank 4 (b + 1) is splitter b
-        const int ns = 4 * nsb;
+        // SPS * nsb regular samples (<= 256), ranked by counting: thread t counts, for sample t mod ns, the smaller samples
+        // among slice t / ns of the sample; the sample of rank SPS (b + 1) is splitter b
+        const int ns = BHV_SPS * nsb;
         const int nsh = 31 - __builtin_clz((unsigned)ns);            // ns is a power of two; j * n_b < 2^21
         if (tid < ns) {
             const int pos = (tid * n_b) >> nsh;
@@ -845,7 +862,7 @@ __global__ void __launch_bounds__(BHV_T, 8) bhv_bucket_kernel(BhvArgs a) {
         __syncthreads();
         if (tid < ns) {
             const unsigned c = srank[tid];
-            if (c != 0u && (c & 3u) == 0u) { ssk[(c >> 2) - 1] = samK[tid]; ssi[(c >> 2) - 1] = samI[tid]; }
+            if (c != 0u && (c & (unsigned)(BHV_SPS - 1)) == 0u) { ssk[(c >> BHV_SPS_LOG) - 1] = samK[tid]; ssi[(c >> BHV_SPS_LOG) - 1] = samI[tid]; }
         }
         __syncthreads();
     }
@@ -863,13 +880,18 @@ __global__ void __launch_bounds__(BHV_T, 8) bhv_bucket_kernel(BhvArgs a) {
             }
         }
         __syncthreads();
-        if (wave == 0) {
-            const unsigned c = lane < nsb ? scount[lane] : 0u;
-            unsigned x = c;
+        if (wave == 0) {                       // lane l: sub-buckets [l * PER, l * PER + PER)
+            constexpr int PER = BHV_NSB_MAX / 64 > 0 ? BHV_NSB_MAX / 64 : 1;
+            unsigned cq[PER], tot = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int sb = lane * PER + q; cq[q] = sb < nsb ? scount[sb] : 0u; tot += cq[q]; }
+            unsigned x = tot;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
-            sstart[lane] = x - c;
-            if (lane == 63) sstart[64] = x;
+            unsigned pre = x - tot;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int sb = lane * PER + q; if (sb < BHV_NSB_MAX) sstart[sb] = pre; pre += cq[q]; }
+            if (lane == 63) sstart[BHV_NSB_MAX] = x;
         }
         __syncthreads();
 #pragma unroll
@@ -1141,8 +1163,9 @@ int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const 
     a.spb = 16;
     a.S = a.spb * B;
     const size_t N = (size_t)n;
-    // one zeroed block: rank[S] | cursor[B] | m_eff | ovf_n | spill_n
-    const size_t zwords = (size_t)a.S + (size_t)B + 8;
+    // one zeroed block: rank[S] | cursor[B] | tile_done[S / 256] | m_eff | ovf_n | spill_n
+    const unsigned gs = (unsigned)sd_ceil_div(a.S, 256);
+    const size_t zwords = (size_t)a.S + (size_t)B + gs + 8;
     unsigned* z = (unsigned*)A.alloc(zwords * 4);
     a.keyS = (uint64_t*)A.alloc((size_t)B * a.cap * 8);
     a.qpart = (uint64_t*)A.alloc(N * 8);
@@ -1158,11 +1181,14 @@ int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const 
         return SDICE_ERR_NOMEM;
     a.rank = z;
     a.cursor = z + a.S;
-    a.m_eff = (unsigned long long*)(a.cursor + B + ((a.S + B) & 1));      // 8-byte aligned
+    a.tile_done = a.cursor + B;
+    a.m_eff = (unsigned long long*)(a.tile_done + gs + ((a.S + B + gs) & 1));      // 8-byte aligned
+    a.spl_k = (uint64_t*)A.alloc((size_t)B * 8);
+    a.spl_i = (uint32_t*)A.alloc((size_t)B * 4);
+    if (!a.spl_k || !a.spl_i) return SDICE_ERR_NOMEM;
     a.ovf_n = a.m_eff + 1;
     a.spill_n = a.m_eff + 2;
     SD_HIP(hipMemsetAsync(z, 0, zwords * 4, ctx->stream));
-    const unsigned gs = (unsigned)sd_ceil_div(a.S, 256);
     SD_LAUNCH(ctx, "bhv_rank_kernel", bhv_rank_kernel, dim3(gs, gs), dim3(256), 0, a);
     const unsigned tiles = (unsigned)sd_ceil_div(n, (int64_t)(BHV_T * BHV_E));
     const size_t lds_t = (size_t)B * 20;
