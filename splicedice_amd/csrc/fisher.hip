@@ -170,15 +170,6 @@ __device__ __forceinline__ void pair_of(int64_t q, int s, int& i, int& j) {
     j = (int)(q - ((int64_t)i * s - (int64_t)i * (i + 1) / 2)) + i + 1;
 }
 
-// One WAVE per junction.  The walk lengths of the pairs of one junction differ by an order of
-// magnitude (they follow the margins), and a loop "for each pair: walk" keeps a wave at the pace of its
-// slowest lane: 27 of 64 lanes were active on average.  Here every lane runs its own stream of pairs
-// q = lane, lane + 64, ... as a small state machine -- idle / walking down / walking up -- and the wave
-// executes walk steps for whoever is walking.  Lanes that finish a pair wait until `refill` of them are
-// idle (the set-up of a pair is ~100 instructions that the whole wave issues), then fetch their next
-// pair together.  Over the ~300 pairs of a lane the lengths average out, so the lanes finish a
-// junction within a few per cent of each other.  The state machine only produces the sum of the ratios;
-// pmf(a) -- nine log-factorial look-ups and an exp -- is applied afterwards in a pass with all lanes busy.
 // (i << 16 | j) of every pair index: the same for every junction, built once per call shape
 __global__ void __launch_bounds__(256) pair_table_kernel(unsigned* __restrict__ tab, int64_t n_pairs, int s) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,20 +182,73 @@ __global__ void __launch_bounds__(256) pair_table_kernel(unsigned* __restrict__ 
 __device__ __forceinline__ double logfact_d(const LfTable& t, double k) {
     return k < (double)t.n ? t.lf[(int)k] : lgamma_beyond_table(k + 1.0);
 }
+// log pmf(a) of a table whose total is beyond the log-factorial table: ONE call site in the pair kernel (nine inlined
+// look-up-or-call selects put nine calls, and their spills, into its loop)
+__device__ __noinline__ double log_pmf_beyond_table(double a, double b, double c, double d) {
+    const double n1 = a + b, n2 = c + d, nn = a + c, mm = b + d;
+    return lgamma(n1 + 1.0) + lgamma(n2 + 1.0) + lgamma(nn + 1.0) + lgamma(mm + 1.0) - lgamma(n1 + n2 + 1.0) - lgamma(a + 1.0) -
+           lgamma(b + 1.0) - lgamma(c + 1.0) - lgamma(d + 1.0);
+}
 
+// p = pmf(a) * sum for the 256 pairs from q0 on, whose sums wait in the ring: the whole wave, four pairs per lane, the
+// p-values leave as contiguous 512-byte pieces.  A function of its own (one call per 256 pairs) so that its registers --
+// nine look-ups, an exp -- are not the state machine's: inlined, it spilled 176 bytes of the walk state inside the loop.
+extern __shared__ double smd[];
+__device__ __noinline__ void pmf_block(int s, double* __restrict__ out, const unsigned* __restrict__ pair_tab, LfTable tab,
+                                       int q0, int n_pairs, int lane) {
+    const double* inc = smd;
+    const double* exc = smd + s;
+    const double* ring = smd + 2 * s;
+#pragma nounroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = q0 + t * 64 + lane;
+        if (q < n_pairs) {
+            const double total = ring[q & 511];
+            const unsigned ij = pair_tab[q];
+            const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+            const double a = inc[i], b = inc[j], c = exc[i], d = exc[j];
+            const double n1 = a + b, n2 = c + d, nn = a + c, mm = b + d, M = n1 + n2;
+            double pv = 1.0;                                           // a zero margin (scipy: p = 1)
+            if (n1 != 0.0 && n2 != 0.0 && nn != 0.0 && mm != 0.0) {
+                double logp;
+                if (M < (double)tab.n) {                               // (the largest of the nine arguments)
+                    const double* lf = tab.lf;
+                    logp = lf[(int)n1] + lf[(int)n2] + lf[(int)nn] + lf[(int)mm] - lf[(int)M] - lf[(int)a] - lf[(int)b] -
+                           lf[(int)c] - lf[(int)d];
+                } else {
+                    logp = log_pmf_beyond_table(a, b, c, d);
+                }
+                pv = exp(logp) * total;
+                pv = pv < 1.0 ? pv : 1.0;
+            }
+            out[q] = pv;
+        }
+    }
+}
+
+// One WAVE per junction.  The walk lengths of the pairs of one junction differ by an order of magnitude (they follow the
+// margins), and a loop "for each pair: walk" keeps a wave at the pace of its slowest lane: 27 of 64 lanes were active on
+// average.  Here every lane is a small state machine -- idle / walking down / walking up -- and the wave issues walk steps
+// for all lanes (see Walk).  Pairs are handed out IN ORDER: when `refill` lanes are idle they take the next pairs q = next,
+// next + 1, ... (a lane's rank among the idle lanes picks its pair; the (i, j) of the next 128 pairs wait in two registers
+// across the wave and come by a lane shuffle), so the lanes finish a junction within one pair of each other and the pairs
+// in flight are a window of ~100 consecutive indices.  Finished sums go to a ring of 512 slots in LDS; as soon as a block
+// of 256 consecutive pairs is complete, the whole wave applies pmf(a) -- nine log-factorial look-ups and an exp, all lanes
+// busy -- and writes the 256 p-values as four contiguous 512-byte pieces.  A p-value is written exactly once and nothing
+// is read back (the version with a statically assigned run of 8 pairs per lane wrote the sums, read them again for the
+// pmf pass and wrote the p-values: 12.9 GB of HBM traffic for 4 GB of results).
 template <int UNROLL, bool COUNT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict__ excl, int64_t n, int s,
                     double* __restrict__ p, LfTable tab, const unsigned* __restrict__ pair_tab, int refill,
                     unsigned long long* __restrict__ row_counter) {
-    // counts staged as doubles (exact below 2^53): the set-up of a pair is then a table look-up, four LDS
-    // reads and a dozen f64 operations, no integer -> double conversions
-    extern __shared__ double smd[];
+    // counts staged as doubles (exact below 2^53): the set-up of a pair is four LDS reads and a dozen f64 operations
     double* inc = smd;
     double* exc = smd + s;
+    double* ring = smd + 2 * s;                                        // [512] finished sums, slot = q mod 512
     const int lane = threadIdx.x;
-    double* run = smd + 2 * s + lane * 10;         // this lane's run of finished sums (80-byte pitch: 16 B aligned, 4-way bank spread)
-    const int64_t n_pairs = (int64_t)s * (s - 1) / 2;
+    const int n_pairs = (int)((int64_t)s * (s - 1) / 2);               // (s <= 8192: fewer than 2^25 pairs)
+    const int n_blk = (n_pairs + 255) >> 8;
     static_assert(UNROLL >= 1 && UNROLL <= 24, "unroll");
     // COUNT (fisher.count_steps, a measurement build): lane-steps issued and lane-steps that advanced a live walk
     // inside its support -- row_counter[1], [2]
@@ -222,35 +266,14 @@ fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict_
             exc[k] = (double)excl[row * s + k];
         }
         __syncthreads();
-        double* out = p + row * n_pairs;
+        double* out = p + row * (int64_t)n_pairs;
 
-        // ---- sums of the ratios: out[q] = 1 + sum over the accepted k != a of pmf(k)/pmf(a)
-        // a lane owns runs of 8 consecutive pairs (q = 512 b + 8 lane + j): finished sums wait in 64 B of LDS and
-        // leave as one contiguous 64-byte piece -- sums written one by one as the lanes drift apart left the L2
-        // as partial lines (PMC: 21.6 GB written for 4 GB of p-values)
-        const bool out16 = ((uintptr_t)out & 15) == 0;                 // (row base; run starts are multiples of 64 B from it)
-        auto deposit = [&](int q, double v) {
-            run[q & 7] = v;
-            if ((q & 7) == 7) {
-                double* o = out + (q - 7);
-                if (out16) {
-                    const double2* r2 = reinterpret_cast<const double2*>(run);
-                    double2* o2 = reinterpret_cast<double2*>(o);
-                    const double2 a0 = r2[0], a1 = r2[1], a2 = r2[2], a3 = r2[3];
-                    o2[0] = a0; o2[1] = a1; o2[2] = a2; o2[3] = a3;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = run[j];
-                }
-            } else if (q + 1 >= (int)n_pairs) {                        // the row's last, incomplete run
-                double* o = out + (q & ~7);
-                for (int j = 0; j <= (q & 7); ++j) o[j] = run[j];
-            }
-        };
-        int q_next = lane * 8, q_cur = 0;                              // (s <= 8192: fewer than 2^25 pairs)
-        const int n_pairs_i = (int)n_pairs;
-        unsigned ij_next = q_next < n_pairs_i ? pair_tab[q_next] : 0u; // always one entry ahead: its latency hides behind a walk
-        int phase = 0;                         // 0 idle, 1 walking down from a, 2 walking up from a
+        int next = 0, fin_blk = 0;             // wave-uniform: next pair to hand out, next block for the pmf pass
+        int done0 = 0, done1 = 0;              // wave-uniform: finished pairs of the even / odd block in the ring
+        int tab_base = 0;                      // pair_tab[tab_base + lane] / [tab_base + 64 + lane] sit in tab_cur / tab_nxt
+        unsigned tab_cur = lane < n_pairs ? pair_tab[lane] : 0u;
+        unsigned tab_nxt = 64 + lane < n_pairs ? pair_tab[64 + lane] : 0u;
+        int phase = 0, q_cur = 0;              // 0 idle, 1 walking down from a, 2 walking up from a
         Walk w;
         w.start(1.0, 1.0, 1.0, 1.0, 0.0);
         // the table [[a, b], [c, d]] of the current pair: down from k = a the ratio is a d / ((b + 1)(c + 1)) over
@@ -258,19 +281,41 @@ fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict_
         // either side (the sum comes out as 1 and the pmf pass sets p = 1, as scipy does).
         double ta = 0.0, tb = 0.0, tc = 0.0, td = 0.0;
         while (true) {
-            const bool can_fetch = phase == 0 && q_next < n_pairs_i;
-            const unsigned long long idle_m = __ballot(phase == 0), fetch_m = __ballot(can_fetch);
-            if (idle_m == ~0ull && fetch_m == 0ull) break;
-            if ((__popcll(fetch_m) >= refill || idle_m == ~0ull) && can_fetch) {
-                const int i = (int)(ij_next >> 16), j = (int)(ij_next & 0xffffu);
-                ta = inc[i]; tb = inc[j]; tc = exc[i]; td = exc[j];
-                q_cur = q_next;
-                q_next += (q_next & 7) == 7 ? 512 - 7 : 1;
-                if (q_next < n_pairs_i) ij_next = pair_tab[q_next];
-                w.start(ta, td, tb + 1.0, tc + 1.0, ta < td ? ta : td);     // down from k = a (possibly no step at all)
-                phase = 1;
+            // ---- p = pmf(a) * sum for a complete block of 256 pairs, all lanes busy
+            if (fin_blk < n_blk) {
+                const int need = min(256, n_pairs - (fin_blk << 8));
+                if (((fin_blk & 1) ? done1 : done0) == need) {
+                    pmf_block(s, out, pair_tab, tab, fin_blk << 8, n_pairs, lane);
+                    if (fin_blk & 1) done1 = 0; else done0 = 0;
+                    fin_blk += 1;
+                }
             }
-            // one trip: every lane steps, whatever its phase (see Walk); the exec mask is not touched
+            // ---- hand out pairs (the ring holds the two blocks from fin_blk on)
+            const unsigned long long idle_m = __ballot(phase == 0);
+            const int lim = min(n_pairs, (fin_blk + 2) << 8);
+            if (idle_m == ~0ull && next >= n_pairs && fin_blk >= n_blk) break;
+            const int n_idle = __popcll(idle_m);
+            if ((n_idle >= refill || idle_m == ~0ull) && next < lim) {
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle_m, 0u));
+                const int q = next + r;
+                const int dq = q - tab_base;                              // < 128 for a lane that takes a pair
+                const unsigned e0 = (unsigned)__shfl((int)tab_cur, dq & 63), e1 = (unsigned)__shfl((int)tab_nxt, dq & 63);
+                if (phase == 0 && q < lim) {
+                    const unsigned ij = dq < 64 ? e0 : e1;
+                    const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+                    ta = inc[i]; tb = inc[j]; tc = exc[i]; td = exc[j];
+                    q_cur = q;
+                    w.start(ta, td, tb + 1.0, tc + 1.0, ta < td ? ta : td);   // down from k = a (possibly no step at all)
+                    phase = 1;
+                }
+                next = min(next + n_idle, lim);
+                if (next >= tab_base + 64) {
+                    tab_base += 64;
+                    tab_cur = tab_nxt;
+                    tab_nxt = tab_base + 64 + lane < n_pairs ? pair_tab[tab_base + 64 + lane] : 0u;
+                }
+            }
+            // ---- one trip: every lane steps, whatever its phase (see Walk); the exec mask is not touched
             if (COUNT) {
                 const double left = (w.dN_end - w.dN) * 0.5;
                 if (phase != 0 && left > 0.0) n_useful += (unsigned long long)(left < (double)UNROLL ? left : (double)UNROLL);
@@ -283,35 +328,21 @@ fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict_
                 if (k % Walk::TRIP == Walk::TRIP - 1 && k + 1 < UNROLL) { w.rescale(); ok = w.eP == 0; }
             }
             w.rescale();
-            if (phase != 0 && (w.at_end() || w.tail_negligible())) {
-                const double up_steps = tb < tc ? tb : tc;
-                if (phase == 1 && up_steps > 0.0) {
+            const bool fin = phase != 0 && (w.at_end() || w.tail_negligible());
+            const double up_steps = tb < tc ? tb : tc;
+            const bool dep = fin && !(phase == 1 && up_steps > 0.0);
+            const unsigned long long dep1 = __ballot(dep && (q_cur & 256) != 0), dep_m = __ballot(dep);
+            done1 += __popcll(dep1);
+            done0 += __popcll(dep_m) - __popcll(dep1);
+            if (fin) {
+                if (!dep) {
                     w.turn(tb, tc, ta + 1.0, td + 1.0, up_steps);                                   // up from k = a
                     phase = 2;
                 } else {
-                    deposit(q_cur, 1.0 + w.sum());
+                    ring[q_cur & 511] = 1.0 + w.sum();
                     phase = 0;
                 }
             }
-        }
-        __syncthreads();
-
-        // ---- p = pmf(a) * sum, all lanes busy
-        for (int64_t q = lane; q < n_pairs; q += 64) {
-            const double total = out[q];
-            const unsigned ij = pair_tab[q];
-            const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
-            const double a = inc[i], b = inc[j], c = exc[i], d = exc[j];
-            const double n1 = a + b, n2 = c + d, nn = a + c, mm = b + d, M = n1 + n2;
-            double pv = 1.0;                                           // a zero margin (scipy: p = 1)
-            if (n1 != 0.0 && n2 != 0.0 && nn != 0.0 && mm != 0.0) {
-                const double logp = logfact_d(tab, n1) + logfact_d(tab, n2) + logfact_d(tab, nn) + logfact_d(tab, mm) -
-                                    logfact_d(tab, M) - logfact_d(tab, a) - logfact_d(tab, b) - logfact_d(tab, c) -
-                                    logfact_d(tab, d);
-                pv = exp(logp) * total;
-                pv = pv < 1.0 ? pv : 1.0;
-            }
-            out[q] = pv;
         }
     }
     if (COUNT) {
@@ -373,7 +404,7 @@ extern "C" int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, cons
     SD_HIP(hipMemsetAsync(row_counter, 0, 24, ctx->stream));
     SD_LAUNCH(ctx, "pair_table_kernel", pair_table_kernel, dim3((unsigned)sd_ceil_div(n_pairs, (int64_t)256)), dim3(256), 0,
               pair_tab, n_pairs, (int)s);
-    const size_t lds = (size_t)s * 16 + 64 * 10 * 8;
+    const size_t lds = (size_t)s * 16 + 512 * 8;
     const bool count = ctx->param("fisher.count_steps", 0) != 0;
     auto kern = count ? (unroll <= 4 ? fisher_pairs_kernel<4, true> : unroll <= 6 ? fisher_pairs_kernel<6, true> : unroll <= 8 ? fisher_pairs_kernel<8, true> :
                          unroll <= 12 ? fisher_pairs_kernel<12, true> : fisher_pairs_kernel<16, true>)
