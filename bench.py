@@ -159,7 +159,7 @@ class QuantWorkload:
     metric = "PS-matrix entries/sec (junctions x samples)"
     unit = "entries/s"
     dtype = "int32 counts -> f32 PS"
-    kernel = "ps_tile_kernel"
+    kernel = "ps_tile_v3_kernel"
 
     DEFAULT_N, DEFAULT_S, DEFAULT_BLOCK = 2_000_000, 500, 200_000      # north_star's target size
 
@@ -318,7 +318,7 @@ class CompareWorkload:
     metric = "junction rank-sum tests/sec (50 v 50)"
     unit = "rows/s"
     dtype = "f32 PS -> f64 p"
-    kernel = "ranksum_pair_kernel"
+    kernel = "ranksum_pairq_kernel"
 
     def __init__(self, ctx, rank, n, s, block_rows=0):
         self.ctx, self.n, self.s = ctx, n or 1_000_000, s or 100
@@ -461,7 +461,7 @@ class E2EWorkload(QuantWorkload):
         self.d_q = ctx.empty(n, np.float64)
         self.collective = "none (1 GPU; N > 1: ShardedE2EWorkload)"
         big = max(self.g1.size, self.g2.size)
-        self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
+        self.kernel = ("ranksum_pairq_kernel" if big > 16 and self.g1.size <= 63 else "ranksum_pair_kernel") if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
         self.alg_bytes = (4.0 * s + 28.0) * n           # rank-sum: 4*S_sel + 28 B per junction
 
     def step(self):
@@ -665,7 +665,7 @@ class ShardedE2EWorkload:
         self.units = self.n * s
         self.alg_bytes = (4.0 * s + 28.0) * self.n
         big = max(self.g1.size, self.g2.size)
-        self.kernel = "ranksum_pair_kernel" if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
+        self.kernel = ("ranksum_pairq_kernel" if big > 16 and self.g1.size <= 63 else "ranksum_pair_kernel") if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
         self.part = part
         del ext, row_ptr, col
 
@@ -802,21 +802,34 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
                 "traffic_source": traffic[1] if traffic else "no PMC pass committed for this shape"}
     if wl.key == "pairwise" and launches:
         # the Fisher kernel is f64-VALU bound: achieved VALU issue against the f64 issue rate of the chip
-        # (tools/mb/microbench.hip: 33.6e12 f64 FMA lane-operations/s = 5.25e11 wave64 instructions/s),
-        # instruction and active-lane counts from the committed SQ counter passes of this shape
+        # (tools/mb/microbench.hip: 33.6e12 f64 FMA lane-operations/s = 5.25e11 wave64 instructions/s), instruction
+        # counts from the committed SQ counter pass of this shape.  The walk step is branch-free (every lane steps in
+        # every trip), so the hardware's active-lane count says nothing; the kernel counts its own lane-steps in one
+        # extra launch outside the timed region (fisher.count_steps): issued, and those that advanced a live walk
+        # inside its support.
+        vf = {"peak": F64_WAVE_INSTS_SPEC, "unit": "wave64 VALU instructions/s (all VALU, f64 and not)",
+              "peak_measured_fma_loop": F64_WAVE_INSTS_PER_S}
+        try:
+            ctx.set_param("fisher.count_steps", 1)
+            ctx.fisher_pairs_dev(wl.d_counts, wl.d_excl, wl.d_p)
+            useful, issued = ctx.fisher_step_stats()
+            ctx.set_param("fisher.count_steps", 0)
+            vf.update({"lane_steps_issued": issued, "lane_steps_useful": useful, "useful_lane_frac": useful / max(issued, 1),
+                       "useful_steps_per_pair": useful / (wl.n * (wl.s * (wl.s - 1) // 2)),
+                       "valu_per_step": 10, "step_valu_rate": issued / 64 * 10 / (avg_ms * 1e-3),
+                       "step_valu_frac_of_peak": issued / 64 * 10 / (avg_ms * 1e-3) / F64_WAVE_INSTS_SPEC})
+        except Exception as e:                                  # noqa: BLE001 (a measurement aid must not fail the line)
+            vf["lane_steps_error"] = str(e)
         try:
             with open(os.path.join(REPO, "profiles", "pairwise_valu.json")) as fh:
                 pv = json.load(fh)
             if pv["n"] == wl.n and pv["s"] == wl.s:
                 rate = pv["SQ_INSTS_VALU_per_launch"] / (avg_ms * 1e-3)
-                lanes = pv["active_lanes_of_64"]
-                roofline["valu_f64"] = {"achieved": rate, "peak": F64_WAVE_INSTS_SPEC, "unit": "wave64 VALU instructions/s (all VALU, f64 and not)",
-                                        "frac": rate / F64_WAVE_INSTS_SPEC, "peak_measured_fma_loop": F64_WAVE_INSTS_PER_S,
-                                        "frac_of_measured": rate / F64_WAVE_INSTS_PER_S, "active_lanes_of_64": lanes,
-                                        "useful_lane_frac": rate / F64_WAVE_INSTS_SPEC * lanes / 64.0,
-                                        "stale": pv.get("src_sha16") != kernel_source_sha16("pairwise"), "source": pv["source"]}
+                vf.update({"achieved": rate, "frac": rate / F64_WAVE_INSTS_SPEC, "frac_of_measured": rate / F64_WAVE_INSTS_PER_S,
+                           "stale": pv.get("src_sha16") != kernel_source_sha16("pairwise"), "source": pv["source"]})
         except (OSError, ValueError, KeyError):
             pass
+        roofline["valu_f64"] = vf
     v = None
     if verify:
         ok, checked = wl.verify()

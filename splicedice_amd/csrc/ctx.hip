@@ -215,10 +215,14 @@ static hipEvent_t pool_get(sdice_ctx* ctx) {
 
 int sd_prof_begin(sdice_ctx* ctx, const char* name) {
     if (!ctx->prof_on) return -1;
-    if (ctx->prof_mode == 2 && strcmp(name, "ps_tile_kernel") != 0 && strcmp(name, "ranksum_wave_kernel") != 0 && strcmp(name, "ranksum_count_kernel") != 0 && strcmp(name, "ranksum_pair_kernel") != 0 && strcmp(name, "ranksum_lane_kernel") != 0 &&
-        strcmp(name, "ranksum_block_kernel") != 0 && strcmp(name, "fisher_pairs_kernel") != 0 &&
-        strcmp(name, "rccl_allgather") != 0)
-        return -1;
+    if (ctx->prof_mode == 2) {          // only the dominant kernel of each path
+        static const char* const kDominant[] = {"ps_tile_v3_kernel", "ps_tile_dma_kernel", "ps_tile_kernel", "ranksum_wave_kernel",
+                                                "ranksum_count_kernel", "ranksum_pair_kernel", "ranksum_pairq_kernel",
+                                                "ranksum_lane_kernel", "ranksum_block_kernel", "fisher_pairs_kernel", "rccl_allgather"};
+        bool hit = false;
+        for (const char* k : kDominant) hit = hit || strcmp(name, k) == 0;
+        if (!hit) return -1;
+    }
     if (ctx->prof_pending.size() >= 8192 && sd_prof_drain(ctx) != SDICE_OK) return -1;
     int id;
     auto it = ctx->prof_ids.find(name);

@@ -962,7 +962,7 @@ template <bool CH, bool WE, bool WP, bool Q3>
 int launch_ps_dma_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_dma_kernel<CH, WE, WP, Q3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_dma_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
+    SD_LAUNCH(ctx, "ps_tile_dma_kernel", (ps_tile_dma_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
     return SDICE_OK;
 }
 template <bool CH>
@@ -978,7 +978,7 @@ template <bool CH, bool WE, bool WP, bool Q3>
 int launch_ps_v3_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_v3_kernel<CH, WE, WP, Q3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "ps_tile_kernel", (ps_tile_v3_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
+    SD_LAUNCH(ctx, "ps_tile_v3_kernel", (ps_tile_v3_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
     return SDICE_OK;
 }
 template <bool CH>

@@ -1357,7 +1357,7 @@ int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int3
     if (blocks > cap) blocks = cap;
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_pairq_kernel<P>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "ranksum_pair_kernel", (ranksum_pairq_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
+    SD_LAUNCH(ctx, "ranksum_pairq_kernel", (ranksum_pairq_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
               s, gsel, n1, n2, stride, o);
     {   // rows marked RS_REDO (a value that is not float32(k/1000)): the float sorting kernel, marked rows only
         const int ww = 4;

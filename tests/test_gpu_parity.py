@@ -601,7 +601,7 @@ def test_device_pipeline_matches_host_calls(ctx):
     ctx.sync()
     rep = ctx.prof_report()
     ctx.prof_enable(False)
-    assert rep["ps_tile_kernel"][0] == 1 and rep["ps_tile_kernel"][1] > 0
+    assert rep["ps_tile_v3_kernel"][0] == 1 and rep["ps_tile_v3_kernel"][1] > 0
     assert np.array_equal(d_ps.to_host(), O.quantize3_fast(ps_host), equal_nan=True)
     g1, g2 = np.arange(0, 20, dtype=np.int32), np.arange(20, 40, dtype=np.int32)
     out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),

@@ -48,7 +48,7 @@ for lds, th, remap, chunk, tr, halo, ab in itertools.product(*[[int(x) for x in 
     ctx.prof_reset()
     for _ in range(a.iters):
         ctx.ps_dev(d_counts, d_rp, d_col, None, d_ps)
-    k, ms = ctx.prof_query("ps_tile_kernel")
+    k, ms = ctx.prof_query("ps_tile_v3_kernel")
     ms /= k
     gbs = a.n * a.s * 8 / ms / 1e6
     res.append((gbs, lds, th, remap, chunk, ms))
