@@ -73,6 +73,8 @@ struct FastArgs {
     int lds_cap;           // elements the sort kernel may hold in LDS
     unsigned long long* sb;   // status block
     uint32_t* rank;        // [S]
+    uint32_t* col_done;    // [ceil(S / 256)] j tiles finished per column of the ranking grid
+    uint64_t* spl;         // [B] splitters (B - 1 used)
     uint32_t* cursor;      // [B]
     uint4* slots;          // [B * slot_cap]
     uint32_t* rowC; uint32_t* rowL; uint32_t* rowR2;   // row-order arrays [n]
@@ -105,8 +107,22 @@ __device__ __forceinline__ uint64_t sample_key(const FastArgs& a, int64_t i) {
     return ((uint64_t)(uint32_t)a.chrom[p] << 32) | (uint64_t)(uint32_t)a.left[p];
 }
 
+// c += (ka, ia) < (kb, ib) in composite order: the borrow of the 96-bit subtraction, added with carry (four VALU
+// instructions; the compiler makes five compares and their mask arithmetic of the || / && form)
+__device__ __forceinline__ void count_less96(unsigned& c, uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+    unsigned t;
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\t"
+        "v_subb_co_u32 %0, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %0, vcc, %6, %7, vcc\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(t), "+v"(c)
+        : "v"(ia), "v"(ib), "v"((unsigned)ka), "v"((unsigned)kb), "v"((unsigned)(ka >> 32)), "v"((unsigned)(kb >> 32))
+        : "vcc");
+}
+
 __global__ void __launch_bounds__(256) sample_rank_kernel(FastArgs a) {
-    __shared__ uint64_t jk[256];
+    __shared__ __align__(16) uint64_t jk[256];
+    __shared__ unsigned last;
     const int t = threadIdx.x;
     // (the status block is first written by the next kernel: cleared here, no launch of its own)
     if (blockIdx.x == 0 && blockIdx.y == 0 && t < SB_WORDS) a.sb[t] = 0ull;
@@ -114,16 +130,32 @@ __global__ void __launch_bounds__(256) sample_rank_kernel(FastArgs a) {
     jk[t] = j < a.S ? sample_key(a, j) : ~0ull;
     const uint64_t ik = i < a.S ? sample_key(a, i) : 0ull;
     __syncthreads();
-    // rank of key i among the sample = #{j : key_j < key_i, or equal and j < i}; j runs over this block's 256 keys
+    // rank of key i among the sample = #{j : key_j < key_i, or equal and j < i}; j runs over this block's 256 keys,
+    // two per 16-byte broadcast read; (key_j, q) < (key_i, split) with q = j - j0, split = i - j0 clamped to [0, 256]
     const int64_t j0 = (int64_t)blockIdx.y * 256;
-    const int64_t split = i - j0;                       // j0 + q < i  <=>  q < split
+    const int64_t split64 = i - j0;                     // j0 + q < i  <=>  q < split
+    const uint32_t split = split64 < 0 ? 0u : split64 > 256 ? 256u : (uint32_t)split64;
     uint32_t cnt = 0;
-#pragma unroll 16
-    for (int q = 0; q < (SD_ABL(a, 8) ? 0 : 256); ++q) {
-        const uint64_t k = jk[q];
-        cnt += (k < ik || (k == ik && q < split)) ? 1u : 0u;
+#pragma unroll 8
+    for (int q = 0; q < (SD_ABL(a, 8) ? 0 : 256); q += 2) {
+        const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(&jk[q]);
+        count_less96(cnt, k2.x, (uint32_t)q, ik, split);
+        count_less96(cnt, k2.y, (uint32_t)q + 1u, ik, split);
     }
     if (i < a.S && cnt) atomicAdd(&a.rank[i], cnt);
+    // the workgroup that completes a column of the grid (all j tiles of these 256 sample keys) reads their final ranks and
+    // writes the splitters -- every spb-th sample key in rank order -- so that the scatter kernel's workgroups load B - 1
+    // finished keys instead of walking the S ranks (up to a dozen dependent global round trips each).  No fence: the adds
+    // are device-scope atomics, performed at the memory side once vmcnt is zero, and the ranks are read back by an atomic
+    // (a release fence writes the L2 back: 50 us in the BH kernel of the same shape).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) last = atomicAdd(&a.col_done[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last && i < a.S) {
+        const uint32_t rk = atomicAdd(&a.rank[i], 0u);
+        if (rk != 0 && rk % (uint32_t)a.spb == 0) a.spl[rk / (uint32_t)a.spb - 1] = ik;                  // slots 0 .. B-2
+    }
 }
 
 // ------------------------------------------------------------------ 2. classify + scatter into slots
@@ -139,14 +171,8 @@ __global__ void __launch_bounds__(T) bucket_scatter_kernel(FastArgs a) {
     __shared__ uint32_t s_bad, s_over;
     const int t = threadIdx.x;
     if (t == 0) { s_bad = 0; s_over = 0; }
-    // every spb-th sample key in rank order is a splitter: each workgroup picks them out of the rank table itself
-    // (S rank reads from L2, B - 1 sample keys) -- a separate 5 us launch did nothing else
-    for (int b = t; b < B; b += T) { spl[b] = ~0ull; cnt[b] = 0; }
-    __syncthreads();
-    for (int q = t; q < a.S; q += T) {
-        const uint32_t rk = a.rank[q];
-        if (rk != 0 && rk % (uint32_t)a.spb == 0) spl[rk / (uint32_t)a.spb - 1] = sample_key(a, q);      // slots 0 .. B-2
-    }
+    // every spb-th sample key in rank order is a splitter (written by the ranking kernel)
+    for (int b = t; b < B; b += T) { spl[b] = b < B - 1 ? a.spl[b] : ~0ull; cnt[b] = 0; }
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * T * SC_KPT;
     uint32_t kc[SC_KPT], kl[SC_KPT], kr[SC_KPT], bk[SC_KPT], lr[SC_KPT];
@@ -1003,9 +1029,10 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
     }
     // zero region: [tile states] (needed by every neighbour run) then [cursor | rank | bmax64]
     const size_t zk4 = (size_t)pl.n_tiles * 8;
-    const size_t zrest = (size_t)a.B * 4 + (size_t)(a.S + 4) * 4 + nb64 * 4;     // cursor | rank | bmax64
+    const size_t n_cd = (size_t)(a.S + 255) / 256 + 4;
+    const size_t zrest = (size_t)a.B * 4 + (size_t)(a.S + 4) * 4 + nb64 * 4 + n_cd * 4;     // cursor | rank | bmax64 | col_done
     const size_t slots_bytes = (size_t)a.B * (size_t)a.slot_cap * 16;
-    const size_t total = zk4 + zrest + slots_bytes + (size_t)n * 12 + (size_t)a.B * 8 + 16 * 4096;
+    const size_t total = zk4 + zrest + slots_bytes + (size_t)n * 12 + (size_t)a.B * 16 + 16 * 4096;
     SD_TRY(ctx->arena.reserve(total, ctx->stream));
     Arena& A = ctx->arena;
     char* z = (char*)A.alloc(zk4 + zrest + 1024);
@@ -1013,7 +1040,8 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
     a.rowC = (uint32_t*)A.alloc((size_t)n * 4);
     a.rowL = (uint32_t*)A.alloc((size_t)n * 4);
     a.rowR2 = (uint32_t*)A.alloc((size_t)n * 4);
-    if (!z || !a.slots || !a.rowC || !a.rowL || !a.rowR2) return SDICE_ERR_NOMEM;
+    a.spl = (uint64_t*)A.alloc((size_t)a.B * 8 + 8);
+    if (!z || !a.slots || !a.rowC || !a.rowL || !a.rowR2 || !a.spl) return SDICE_ERR_NOMEM;
     pl.zero_base = z;
     pl.k4_zero_bytes = zk4;
     pl.zero_bytes = zk4 + zrest;
@@ -1022,6 +1050,7 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
     a.cursor = (uint32_t*)(z + zk4);
     a.rank = a.cursor + a.B;
     a.bmax64 = a.rank + a.S + 4;
+    a.col_done = a.bmax64 + nb64;
     a.row_of = d_row_of; a.row_ptr = d_row_ptr;
     a.ablate = (int)ctx->param("cluster.ablate", 0);
     return SDICE_OK;
