@@ -52,7 +52,7 @@ struct BhsArgs {
     uint16_t* bid_cm;       // [segs][m] bucket of each value
     uint64_t* bmin;         // [segs][B]
     uint64_t* sfx;          // [segs][B] minimum over the LATER buckets
-    unsigned* big_count;    // [2] buckets of 257..512 values / of more: work lists of the second and third bucket kernel
+    unsigned* big_count;    // buckets of more than 256 values: work list of the second bucket kernel
     int64_t* big_list;      // [segs * B]
     int reg_cap;            // buckets beyond this many values take the in-HBM path (1024; lower in tests)
 };
@@ -474,33 +474,18 @@ __global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int blocks_p
     if (r.n_b <= 256 && r.n_b <= a.reg_cap) {
         bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
     } else if (lane == 0) {
-        // two work lists in one array: buckets of 257..512 values from the front (8 keys per lane: ~75 VGPRs, six
-        // waves per SIMD), the others from the back (16 keys per lane or the in-HBM network: 150 VGPRs, three waves --
-        // one kernel for both held the 8-key buckets, a fifth of all buckets at a mean of 200, to three waves too)
-        if (r.n_b <= 512 && r.n_b <= a.reg_cap) a.big_list[atomicAdd(a.big_count, 1u)] = g;
-        else a.big_list[(int64_t)a.segs * a.B - 1 - atomicAdd(a.big_count + 1, 1u)] = g;
-    }
-}
-
-__global__ void __launch_bounds__(256) bhs_bucket_mid_kernel(BhsArgs a) {
-    const int lane = threadIdx.x & 63;
-    const unsigned n_mid = a.big_count[0];
-    const unsigned waves = gridDim.x * 4;
-#pragma nounroll
-    for (unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_mid; w += waves) {
-        const BucketRef r = bucket_ref(a, a.big_list[w]);
-        bucket_in_regs<8>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+        const unsigned slot = atomicAdd(a.big_count, 1u);
+        a.big_list[slot] = g;
     }
 }
 
 __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
     const int lane = threadIdx.x & 63;
-    const unsigned n_big = a.big_count[1];
+    const unsigned n_big = *a.big_count;
     const unsigned waves = gridDim.x * 4;
-    const int64_t last = (int64_t)a.segs * a.B - 1;
 #pragma nounroll
     for (unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_big; w += waves) {
-        const BucketRef r = bucket_ref(a, a.big_list[last - w]);
+        const BucketRef r = bucket_ref(a, a.big_list[w]);
         if (r.n_b > a.reg_cap && !r.pd) bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
         else if (r.n_b <= 256) bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
         else if (r.n_b <= 512) bucket_in_regs<8>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
@@ -1128,10 +1113,8 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * blocks_per_seg;
     SD_ARG(bucket_blocks < ((int64_t)1 << 31), "bh: too many buckets");
     SD_LAUNCH(ctx, "bhs_bucket_kernel", bhs_bucket_kernel, dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
-    SD_LAUNCH(ctx, "bhs_bucket_mid_kernel", bhs_bucket_mid_kernel,
-              dim3((unsigned)std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 6)), dim3(256), 0, a);
     SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel,
-              dim3((unsigned)std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 3)), dim3(256), 0, a);
+              dim3((unsigned)std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4)), dim3(256), 0, a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);
     const int64_t gx = sd_ceil_div(m, (int64_t)32);
     for (int64_t c0 = 0; c0 < segs; c0 += (int64_t)65535 * 32) {
