@@ -182,8 +182,7 @@ __global__ void __launch_bounds__(256) pair_table_kernel(unsigned* __restrict__ 
 __device__ __forceinline__ double logfact_d(const LfTable& t, double k) {
     return k < (double)t.n ? t.lf[(int)k] : lgamma_beyond_table(k + 1.0);
 }
-// log pmf(a) of a table whose total is beyond the log-factorial table: ONE call site in the pair kernel (nine inlined
-// look-up-or-call selects put nine calls, and their spills, into its loop)
+// log pmf(a) of a table whose total is beyond the log-factorial table
 __device__ __noinline__ double log_pmf_beyond_table(double a, double b, double c, double d) {
     const double n1 = a + b, n2 = c + d, nn = a + c, mm = b + d;
     return lgamma(n1 + 1.0) + lgamma(n2 + 1.0) + lgamma(nn + 1.0) + lgamma(mm + 1.0) - lgamma(n1 + n2 + 1.0) - lgamma(a + 1.0) -
@@ -191,14 +190,18 @@ __device__ __noinline__ double log_pmf_beyond_table(double a, double b, double c
 }
 
 // p = pmf(a) * sum for the 256 pairs from q0 on, whose sums wait in the ring: the whole wave, four pairs per lane, the
-// p-values leave as contiguous 512-byte pieces.  A function of its own (one call per 256 pairs) so that its registers --
-// nine look-ups, an exp -- are not the state machine's: inlined, it spilled 176 bytes of the walk state inside the loop.
+// p-values leave as contiguous 512-byte pieces.  No call in here: a table whose total lies beyond the log-factorial table
+// (counts above fisher.table_max, 2^20 by default) leaves MINUS its sum (sums are >= 1) and raises the junction's flag;
+// fisher_beyond_table_kernel finishes those junctions.  (A call to lgamma -- even one, in a cold branch -- makes the
+// register allocator keep the walk state in the 48 callee-saved VGPRs and spill the rest inside the loop; a pmf pass in
+// a function of its own saved and restored 112 bytes per lane per call: 14 GB of scratch traffic per launch.)
 extern __shared__ double smd[];
-__device__ __noinline__ void pmf_block(int s, double* __restrict__ out, const unsigned* __restrict__ pair_tab, LfTable tab,
-                                       int q0, int n_pairs, int lane) {
+__device__ __forceinline__ bool pmf_block(int s, double* __restrict__ out, const unsigned* __restrict__ pair_tab, LfTable tab,
+                                          int q0, int n_pairs, int lane) {
     const double* inc = smd;
     const double* exc = smd + s;
     const double* ring = smd + 2 * s;
+    bool beyond = false;
 #pragma nounroll
     for (int t = 0; t < 4; ++t) {
         const int q = q0 + t * 64 + lane;
@@ -210,18 +213,41 @@ __device__ __noinline__ void pmf_block(int s, double* __restrict__ out, const un
             const double n1 = a + b, n2 = c + d, nn = a + c, mm = b + d, M = n1 + n2;
             double pv = 1.0;                                           // a zero margin (scipy: p = 1)
             if (n1 != 0.0 && n2 != 0.0 && nn != 0.0 && mm != 0.0) {
-                double logp;
                 if (M < (double)tab.n) {                               // (the largest of the nine arguments)
                     const double* lf = tab.lf;
-                    logp = lf[(int)n1] + lf[(int)n2] + lf[(int)nn] + lf[(int)mm] - lf[(int)M] - lf[(int)a] - lf[(int)b] -
-                           lf[(int)c] - lf[(int)d];
+                    const double logp = lf[(int)n1] + lf[(int)n2] + lf[(int)nn] + lf[(int)mm] - lf[(int)M] - lf[(int)a] -
+                                        lf[(int)b] - lf[(int)c] - lf[(int)d];
+                    pv = exp(logp) * total;
+                    pv = pv < 1.0 ? pv : 1.0;
                 } else {
-                    logp = log_pmf_beyond_table(a, b, c, d);
+                    pv = -total;
+                    beyond = true;
                 }
-                pv = exp(logp) * total;
-                pv = pv < 1.0 ? pv : 1.0;
             }
             out[q] = pv;
+        }
+    }
+    return beyond;
+}
+
+// the junctions flagged by the pair kernel: p = pmf(a) * sum with lgamma for the pairs that carry a negative sum
+__global__ void __launch_bounds__(256) fisher_beyond_table_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict__ excl,
+                                                                  int64_t n, int s, double* __restrict__ p,
+                                                                  const unsigned* __restrict__ pair_tab,
+                                                                  const unsigned char* __restrict__ row_flag) {
+    const int64_t row = blockIdx.x;
+    if (row >= n || !row_flag[row]) return;
+    const int64_t n_pairs = (int64_t)s * (s - 1) / 2;
+    double* out = p + row * n_pairs;
+    for (int64_t q = threadIdx.x; q < n_pairs; q += 256) {
+        const double v = out[q];
+        if (v < 0.0) {
+            const unsigned ij = pair_tab[q];
+            const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+            const double a = (double)incl[row * s + i], b = (double)incl[row * s + j];
+            const double c = (double)excl[row * s + i], d = (double)excl[row * s + j];
+            const double pv = exp(log_pmf_beyond_table(a, b, c, d)) * -v;
+            out[q] = pv < 1.0 ? pv : 1.0;
         }
     }
 }
@@ -238,10 +264,10 @@ __device__ __noinline__ void pmf_block(int s, double* __restrict__ out, const un
 // is read back (the version with a statically assigned run of 8 pairs per lane wrote the sums, read them again for the
 // pmf pass and wrote the p-values: 12.9 GB of HBM traffic for 4 GB of results).
 template <int UNROLL, bool COUNT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8)))
 fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict__ excl, int64_t n, int s,
                     double* __restrict__ p, LfTable tab, const unsigned* __restrict__ pair_tab, int refill,
-                    unsigned long long* __restrict__ row_counter) {
+                    unsigned long long* __restrict__ row_counter, unsigned char* __restrict__ row_flag) {
     // counts staged as doubles (exact below 2^53): the set-up of a pair is four LDS reads and a dozen f64 operations
     double* inc = smd;
     double* exc = smd + s;
@@ -285,7 +311,7 @@ fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict_
             if (fin_blk < n_blk) {
                 const int need = min(256, n_pairs - (fin_blk << 8));
                 if (((fin_blk & 1) ? done1 : done0) == need) {
-                    pmf_block(s, out, pair_tab, tab, fin_blk << 8, n_pairs, lane);
+                    if (__ballot(pmf_block(s, out, pair_tab, tab, fin_blk << 8, n_pairs, lane)) != 0ull && lane == 0) row_flag[row] = 1;
                     if (fin_blk & 1) done1 = 0; else done0 = 0;
                     fin_blk += 1;
                 }
@@ -392,18 +418,20 @@ extern "C" int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, cons
     SD_HIP(hipSetDevice(ctx->device));
     LfTable t;
     SD_TRY(get_lf_table(ctx, &t));
-    int refill = (int)ctx->param("fisher.refill", 16);
+    int refill = (int)ctx->param("fisher.refill", 12);
     if (refill < 1) refill = 1;
     if (refill > 64) refill = 64;
-    // steps per trip: 16 on 128 VGPRs (four waves per SIMD, no spill) measured 15.5 ms per 25 000 x 19 900 against 16.8 for 8 steps;
-    // on 96 VGPRs (five waves) the walk state spilled inside the loop: 18.2 ms at 8 steps, 34-43 ms at 12-16
+    // steps per trip: 16 (153 VGPRs, three waves per SIMD, nothing spilled) 16.0 ms per 25 000 x 19 900; 8 (114 VGPRs, four
+    // waves) 16.6 ms; 16 under a 128-VGPR cap spills 100 bytes inside the loop: 18.5 ms; under 96 (five waves): 34-43 ms
     const int unroll = (int)ctx->param("fisher.unroll", 16);
     const int64_t n_pairs = (int64_t)s * (s - 1) / 2;
-    SD_TRY(ctx->arena.reserve((size_t)n_pairs * 4 + 8192, ctx->stream));
+    SD_TRY(ctx->arena.reserve((size_t)n_pairs * 4 + (size_t)n + 8192, ctx->stream));
     unsigned* pair_tab = (unsigned*)ctx->arena.alloc((size_t)n_pairs * 4);
     unsigned long long* row_counter = (unsigned long long*)ctx->arena.alloc(24);     // + the two step counters
-    if (!pair_tab || !row_counter) return SDICE_ERR_NOMEM;
+    unsigned char* row_flag = (unsigned char*)ctx->arena.alloc((size_t)n);
+    if (!pair_tab || !row_counter || !row_flag) return SDICE_ERR_NOMEM;
     SD_HIP(hipMemsetAsync(row_counter, 0, 24, ctx->stream));
+    SD_HIP(hipMemsetAsync(row_flag, 0, (size_t)n, ctx->stream));
     SD_LAUNCH(ctx, "pair_table_kernel", pair_table_kernel, dim3((unsigned)sd_ceil_div(n_pairs, (int64_t)256)), dim3(256), 0,
               pair_tab, n_pairs, (int)s);
     const size_t lds = (size_t)s * 16 + 512 * 8;
@@ -420,7 +448,10 @@ extern "C" int sdice_fisher_pairs_dev(sdice_ctx* ctx, int64_t n, int32_t s, cons
     if (per_cu < 1) per_cu = 1;
     int64_t blocks = std::min<int64_t>(n, (int64_t)ctx->n_cu * per_cu);     // the resident waves; junctions by counter
     SD_LAUNCH(ctx, "fisher_pairs_kernel", kern, dim3((unsigned)blocks), dim3(64), lds, d_incl, d_excl, n, (int)s, d_p, t,
-              pair_tab, refill, row_counter);
+              pair_tab, refill, row_counter, row_flag);
+    // junctions with a table beyond the log-factorial table (their workgroups return at once otherwise)
+    SD_LAUNCH(ctx, "fisher_beyond_table_kernel", fisher_beyond_table_kernel, dim3((unsigned)n), dim3(256), 0, d_incl, d_excl, n,
+              (int)s, d_p, pair_tab, row_flag);
     if (count) {
         SD_HIP(hipMemcpyAsync(ctx->fisher_steps, row_counter + 1, 16, hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(hipStreamSynchronize(ctx->stream));

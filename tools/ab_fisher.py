@@ -7,7 +7,7 @@ from splicedice_amd import synth
 from splicedice_amd.engine import Context
 n, s = int(sys.argv[1]), int(sys.argv[2])
 cfgs = sys.argv[3:] or [""]
-DEFAULTS = {"fisher.refill": 16, "fisher.unroll": 16, "fisher.count_steps": 0}
+DEFAULTS = {"fisher.refill": 12, "fisher.unroll": 16, "fisher.count_steps": 0}
 ctx = Context(0)
 junc = synth.make_junctions(n, 4)
 counts_in = synth.make_counts(n, s, 40)
