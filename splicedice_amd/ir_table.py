@@ -11,8 +11,10 @@ runs on the GPU once for the whole count table (sdice_ps with the `excl` output 
 cluster file), the per-line arithmetic and the text stay on the host as in the reference.
 
 Behaviour kept, including the reference's quirks: samples come in os.listdir order; a neighbour missing
-from the count table is reported as "mxCluster ..." and skipped; a junction missing from a sample's counts
-prints "cluster ..." and ends that sample's file; 0/0 is NaN; junctions are kept when ANY sample's RSD is
+from the count table is reported as "mxCluster ..." and skipped; a junction missing from a sample's counts,
+a junction without a line in the cluster file and a sample without a count column each print "cluster ..."
+and end that sample's file (the rows it then lacks make the writers die on a KeyError, as in the reference);
+count tables that are not integer-valued are summed in float64 in the reference's order; 0/0 is NaN; junctions are kept when ANY sample's RSD is
 below the threshold, which needs -r (without it the reference dies on RSD[sample][junction]: KeyError, so
 does this).
 """
@@ -82,23 +84,29 @@ def get_clusters(filename):
     return clusters
 
 
-def cluster_sums(ctx, counts, index, clusters, wanted):
-    """excl[r, :] = sum of the count rows of the neighbours of event r that are present in the table
-    (every listed name counts, as the reference's loop adds them one by one) -- on the GPU for the whole
-    table at once.  Only the events in `wanted` get a list (the reference never looks the others up)."""
+def cluster_sums(ctx, counts, index, clusters, wanted, own_first=False):
+    """sum of the count rows of the neighbours of event r that are present in the table (every listed name counts, as
+    the reference's loop adds them one by one) -- on the GPU for the whole table at once.  Only the events in `wanted`
+    get a list (the reference never looks the others up); an event without a line in the cluster file gets none (the
+    caller reports it as the reference does).  Integer tables: int64 sums of the neighbours.  Float tables
+    (`own_first`): float64 sums in the reference's order -- the event's own count first, then the neighbours in list
+    order, one IEEE addition each (ir_table.py:122-126)."""
     n = counts.shape[0]
     row_ptr = np.zeros(n + 1, dtype=np.int64)
     col = []
     lists = {}
     for name in wanted:
         r = index.get(name)
-        if r is None:
+        if r is None or name not in clusters:
             continue
-        lists[r] = [index[mx] for mx in clusters[name] if mx in index]     # KeyError for an unknown junction, as the reference
+        lists[r] = ([r] if own_first else []) + [index[mx] for mx in clusters[name] if mx in index]
     for r in range(n):
         col.extend(lists.get(r, ()))
         row_ptr[r + 1] = len(col)
-    return ctx.ps(counts, row_ptr, np.asarray(col, dtype=np.int32), want_excl=True, want_ps=False)
+    col = np.asarray(col, dtype=np.int32)
+    if own_first:
+        return ctx.excl_f64(counts, row_ptr, col)
+    return ctx.ps(counts, row_ptr, col, want_excl=True, want_ps=False)
 
 
 def run_with(args, ctx=None):
@@ -109,7 +117,12 @@ def run_with(args, ctx=None):
     print("Gathering inclusion counts and clusters...")
     header, events, mat = textio.read_table_numeric(args.inclusionCounts, np.float64)
     table_samples = header.rstrip().split("\t")[1:]
-    counts = textio.counts_to_int32(mat, args.inclusionCounts)
+    # integer-valued tables take the integer kernel; anything else the reference reads with float() (normalised or
+    # fractional counts) goes through the float64 sums in the reference's order of additions
+    mat = np.asarray(mat, dtype=np.float64)
+    integral = bool(mat.size == 0 or (np.isfinite(mat).all() and (mat >= 0).all() and (mat < 2 ** 31).all()
+                                      and (mat == np.floor(mat)).all()))
+    counts = mat.astype(np.int32) if integral else mat
     index = {name: r for r, name in enumerate(events)}          # (a repeated row name: the last one wins, as the dict does)
     column = {s: c for c, s in enumerate(table_samples)}
     annotated = get_annotated(args.annotation) if not args.allJunctions else None
@@ -135,7 +148,7 @@ def run_with(args, ctx=None):
         own_ctx = ctx is None
         ctx = ctx if ctx is not None else Context(0)
         try:
-            excl = cluster_sums(ctx, counts, index, clusters, wanted)
+            excl = cluster_sums(ctx, counts, index, clusters, wanted, own_first=not integral)
         finally:
             if own_ctx:
                 ctx.close()
@@ -143,7 +156,7 @@ def run_with(args, ctx=None):
     IR, RSD, junctions = {}, {}, set()
     for sample in samples:
         IR[sample], RSD[sample] = {}, {}
-        col_s = column[sample]                                  # KeyError for a sample without a count column, as the reference
+        col_s = column.get(sample)
         for cluster, median, cov_text in lines[sample]:
             junctions.add(cluster)
             if args.makeRSDtable:
@@ -151,7 +164,9 @@ def run_with(args, ctx=None):
                 with np.errstate(all="ignore"):
                     RSD[sample][cluster] = np.std(cov) / np.mean(cov)
             r = index.get(cluster)
-            if r is None:
+            # the reference's outer try (ir_table.py:121-136): a sample without a count column, a junction without a count
+            # row, a junction without a line in the cluster file -- each a KeyError there -- print this and end the sample
+            if r is None or col_s is None or (clusters is not None and cluster not in clusters):
                 print("cluster", sample, cluster)
                 break
             intron = float(counts[r, col_s])
@@ -159,7 +174,7 @@ def run_with(args, ctx=None):
                 for mx in clusters[cluster]:
                     if mx not in index:
                         print("mxCluster", sample, cluster, mx)
-                intron += float(excl[r, col_s])
+                intron = float(excl[r, col_s]) if not integral else intron + float(excl[r, col_s])
             try:
                 IR[sample][cluster] = median / (median + intron)
             except ZeroDivisionError:

@@ -93,6 +93,52 @@ def main():
         with open(prefix + "_stdout.txt", "w") as fh:
             fh.write("\n".join(lines_out) + "\n")
         print(tag, "->", sorted(f for f in os.listdir(out) if f.startswith(f"expected_{tag}")))
+    edge_cases(IT, out, counts_path, clusters_path, chosen)
+
+
+def edge_cases(IT, base, counts_path, clusters_path, chosen):
+    """tests/golden/ir_table_edge: what the reference does (stdout, exception, files) when a junction has no line in the
+    cluster file, when a coverage file belongs to a sample without a count column, and on a fractional count table"""
+    import warnings
+    out = os.path.join(HERE, "ir_table_edge")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    cov = os.path.join(base, "coverage")
+    # (a) the 7th chosen junction loses its line in the cluster file
+    victim = chosen[6]
+    with open(clusters_path) as fh, open(os.path.join(out, "noline_allClusters.tsv"), "w") as dst:
+        dst.write("".join(line for line in fh if line.split("\t")[0].rstrip("\n") != victim))
+    # (b) coverage directory with one more sample than the count table has columns
+    ghost = os.path.join(out, "coverage_ghost")
+    shutil.copytree(cov, ghost)
+    first = sorted(f for f in os.listdir(cov) if f.endswith("_intron_coverage.txt"))[0]
+    shutil.copy(os.path.join(cov, first), os.path.join(ghost, "ghost_intron_coverage.txt"))
+    # (c) a normalised (fractional) count table
+    with open(counts_path) as fh, open(os.path.join(out, "frac_inclusionCounts.tsv"), "w") as dst:
+        dst.write(fh.readline())
+        for k, line in enumerate(fh):
+            f = line.rstrip("\n").split("\t")
+            dst.write(f[0] + "\t" + "\t".join(repr(float(v) * (0.37 + 0.01 * (k % 7)) + (0.125 if k % 5 == 0 else 0.0)) for v in f[1:]) + "\n")
+    cases = {"noline": dict(inclusionCounts=counts_path, clusters=os.path.join(out, "noline_allClusters.tsv"), coverageDirectory=cov),
+             "ghost": dict(inclusionCounts=counts_path, clusters=clusters_path, coverageDirectory=ghost),
+             "frac": dict(inclusionCounts=os.path.join(out, "frac_inclusionCounts.tsv"), clusters=clusters_path, coverageDirectory=cov)}
+    for tag, kw in cases.items():
+        prefix = os.path.join(out, f"expected_{tag}")
+        args = argparse.Namespace(outputPrefix=prefix, makeRSDtable=True, annotation=os.path.join(base, "anno.gtf"), RSDthreshold=1.0,
+                                  allJunctions=True, singleJunctionCalculation=False, **kw)
+        buf, exc = io.StringIO(), "none"
+        with contextlib.redirect_stdout(buf), np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                IT.run_with(args)
+            except Exception as e:                      # noqa: BLE001 (the point is to record what the reference raises)
+                exc = type(e).__name__
+        lines_out = [ln for ln in buf.getvalue().splitlines() if not ln.startswith("Done")]
+        with open(prefix + "_stdout.txt", "w") as fh:
+            fh.write("\n".join(lines_out) + "\n")
+        with open(prefix + "_exception.txt", "w") as fh:
+            fh.write(exc + "\n")
+        print("edge", tag, exc, "->", sorted(f for f in os.listdir(out) if f.startswith(f"expected_{tag}")))
 
 
 if __name__ == "__main__":
