@@ -661,7 +661,9 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 // XCD starts its workgroups in increasing id order, so the smallest unfinished tile is always running
 // and every wait ends; HIP does not promise that order, hence the spin is bounded: a wait that
 // outlasts ~1 s gives up, flags ST_LOOKBACK (the chain's result is then discarded and the caller
-// falls back to the generic path) and the grid drains.
+// falls back to the generic path) and the grid drains.  (A device-side ticket would turn the order into a guarantee; it was
+// measured: one atomic counter hands out ~90 tickets per microsecond, and a ticket per tile alone bounded this kernel at
+// 22 us for 1 954 tiles, a third of its run time -- DESIGN.md, Appendix A.2.)
 __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* state, int tile, unsigned long long agg,
                                                                  int lane, unsigned long long* sb) {
     if (lane == 0) st_agent(&state[tile], (tile == 0 ? LB_P : LB_A) | agg);
@@ -1232,7 +1234,7 @@ extern "C" int sdice_cluster_dev(sdice_ctx* ctx, int64_t n, const int32_t* d_chr
         SD_TRY(sd_cluster_check_nnz(ctx, nnz, false));
         SD_TRY(ensure_col(ctx, nnz + nnz / 8 + 1024));
         SD_HIP(hipMemsetAsync(pl.zero_base, 0, pl.k4_zero_bytes, ctx->stream));
-        // flags, ticket, total and reach start over; the maximum length (words SB_MAXLEN..) stays
+        // flags, total and reach start over; the maximum length (words SB_MAXLEN..) stays
         SD_HIP(hipMemsetAsync(a.sb, 0, (size_t)SB_MAXLEN * 8, ctx->stream));
         SD_HIP(hipMemsetAsync(a.sb + SB_REACH, 0, (size_t)SB_SLOTS * 8, ctx->stream));
         SD_TRY(launch_neighbours(ctx, pl));
