@@ -17,6 +17,8 @@ Generators
   fisher    random count rows through fisher_pairs (pair table, long walks) against scipy
   bh        per-column sample-sort path against the generic path (bit for bit) and the oracle: tie structures,
             sizes around the bucket limits
+  bh_vector one long vector (16 384..2 Mi values): the sample-sort path against the radix path, bit for bit, plain and masked,
+            tie structures, some buckets forced beyond their slot
   cluster_big  70 k..2.6 M skewed junctions (a tenth in one locus, 5 000 sharing one left end, unequal chromosomes):
             the fast path against the generic radix-sort path, both on the GPU
   chi2, quantize   --chi2 p-values against scipy; the '.3f' round trip around every rounding boundary
@@ -295,8 +297,51 @@ def gen_bh(ctx, rng):
     return None
 
 
+def gen_bh_vector(ctx, rng):
+    """one long vector: the sample-sort path (bhv_*) against the radix path, bit for bit, plain and masked"""
+    n = int(rng.choice([16384, 16385, 20000, 65536, 100_003, 262_144, 700_001, 1_048_576, 2_097_152]))
+    p = rng.random(n) ** float(rng.choice([1, 3, 20]))
+    kind = int(rng.integers(0, 7))
+    if kind == 1:
+        p[rng.random(n) < 0.6] = 1.0
+    elif kind == 2:
+        p[:] = rng.choice([1.0, 0.5, 0.0286, 0.2, 1e-5], size=n)
+    elif kind == 3:
+        p[:] = 0.125                                          # ONE value: every split is by index
+    elif kind == 4:
+        p[:] = 0.5 + rng.integers(0, 9, size=n) * 2.0 ** -53
+    elif kind == 5:
+        p[:] = np.sort(p)[::-1] if rng.random() < 0.5 else np.sort(p)
+    elif kind == 6:
+        p[: n // 3] = 0.0
+        p[n // 3: n // 2] = 5e-324
+    frac = float(rng.choice([1.0, 0.95, 0.5, 0.02]))
+    tested = (rng.random(n) < frac).astype(np.uint8)
+    cap = int(rng.choice([5632, 5632, 5632, 3072]))           # a small capacity sends some buckets through the slow path
+    out = {}
+    try:
+        for path in (1, 2):
+            ctx.set_param("bh.vector_path", path)
+            ctx.set_param("bhv.cap", cap)
+            d_p, d_q = ctx.to_device(p), ctx.empty(n, np.float64)
+            ctx.bh_dev(d_p, d_q)
+            a = d_q.to_host()
+            d_t = ctx.to_device(tested)
+            ctx.bh_masked_dev(d_p, d_t, d_q)
+            out[path] = (a, d_q.to_host())
+    finally:
+        ctx.set_param("bh.vector_path", 0)
+        ctx.set_param("bhv.cap", 5632)
+    for k, what in ((0, "plain"), (1, "masked")):
+        if not np.array_equal(out[1][k].view(np.uint64), out[2][k].view(np.uint64)):
+            return f"bh vector ({what}): sample-sort path != radix path (n={n} kind={kind} tested={frac} cap={cap})"
+    if n <= 70000 and not np.allclose(out[2][0], O.bh_fdr(p), rtol=1e-14, atol=0):
+        return f"bh vector differs from the oracle (n={n} kind={kind})"
+    return None
+
+
 GENERATORS = {"cluster": gen_cluster, "ps": gen_ps, "ps_f64": gen_ps_f64, "ranksum": gen_ranksum, "fisher": gen_fisher,
-              "bh": gen_bh, "cluster_big": gen_cluster_big, "chi2": gen_chi2, "quantize": gen_quantize}
+              "bh": gen_bh, "bh_vector": gen_bh_vector, "cluster_big": gen_cluster_big, "chi2": gen_chi2, "quantize": gen_quantize}
 
 
 def rss_gib():
