@@ -133,7 +133,7 @@ __device__ __forceinline__ float median_sorted(const float* a, int nv) {
 
 template <int P>
 __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restrict__ ps, int64_t n, int s,
-                                                           const int32_t* __restrict__ gsel, int n1, int n2,
+                                                           const int32_t* __restrict__ gsel1, const int32_t* __restrict__ gsel2, int n1, int n2,
                                                            int stride, RsOut o, int ablate) {
     extern __shared__ float smemf[];
     const int lane = threadIdx.x & 63;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restri
     float* tile = smemf + (size_t)wave * 64 * stride;
     const int nsel = n1 + n2;
     int* selL = reinterpret_cast<int*>(smemf + (size_t)waves_per_block * 64 * stride);
-    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = k < n1 ? gsel1[k] : gsel2[k - n1];
     __syncthreads();
     const int64_t n_groups = (n + 63) >> 6;
     for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restri
 // the pair adds them: 2U = sum_i lb_i + ub_i.  No tie-run bookkeeping in either merge.
 template <int P>
 __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restrict__ ps, int64_t n, int s,
-                                                           const int32_t* __restrict__ gsel, int n1, int n2,
+                                                           const int32_t* __restrict__ gsel1, const int32_t* __restrict__ gsel2, int n1, int n2,
                                                            int stride, RsOut o) {
     extern __shared__ float smemp[];
     const int lane = threadIdx.x & 63;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restri
     float* tile = smemp + (size_t)wave * 32 * stride;
     const int nsel = n1 + n2;
     int* selL = reinterpret_cast<int*>(smemp + (size_t)waves_per_block * 32 * stride);
-    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = k < n1 ? gsel1[k] : gsel2[k - n1];
     __syncthreads();
     const int64_t n_groups = (n + 31) >> 5;
     for (int64_t g = (int64_t)blockIdx.x * waves_per_block + wave; g < n_groups;
@@ -411,7 +411,7 @@ __device__ __forceinline__ void sort_keys16(uint32_t (&k)[P / 2]) {
 
 template <int P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) ranksum_pairq_kernel(const float* __restrict__ ps, int64_t n, int s,
-                                                            const int32_t* __restrict__ gsel, int n1, int n2,
+                                                            const int32_t* __restrict__ gsel1, const int32_t* __restrict__ gsel2, int n1, int n2,
                                                             int stride /* u16 units, odd multiple ... */, RsOut o) {
     extern __shared__ float smemq[];
     constexpr int NR = P / 2;
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int nsel = n1 + n2;
     int* selL = reinterpret_cast<int*>(smemq);                          // [nsel]
     unsigned short* tile = reinterpret_cast<unsigned short*>(selL + ((nsel + 1) & ~1)) + (size_t)wave * 32 * stride;
-    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = gsel[k];
+    for (int k = threadIdx.x; k < nsel; k += blockDim.x) selL[k] = k < n1 ? gsel1[k] : gsel2[k - n1];
     // every slot of the tile starts as 0xFFFF ("no value"): the staging only ever writes the first n1 / n2 slots of a
     // group and the sorted write-back leaves 0xFFFF in the others, so the slots behind a group never need a bound check
     for (int k = lane; k < 16 * stride; k += 64) reinterpret_cast<u32_alias*>(tile)[k] = 0xFFFFFFFFu;
@@ -1310,7 +1310,7 @@ int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
 }
 
 template <int P>
-int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2, RsOut o) {
+int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* g1, int n1, const int32_t* g2, int n2, RsOut o) {
     const int stride = (n1 + n2) | 1;
     int waves = 2;
     const size_t lds = (size_t)waves * 64 * stride * 4 + (size_t)(n1 + n2) * 4;
@@ -1321,14 +1321,14 @@ int launch_lane(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_lane_kernel<P>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_LAUNCH(ctx, "ranksum_lane_kernel", (ranksum_lane_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
-              s, gsel, n1, n2, stride, o, (int)ctx->param("ranksum.ablate", 0));
+              s, g1, g2, n1, n2, stride, o, (int)ctx->param("ranksum.ablate", 0));
     SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
               o.p, o.z);
     return SDICE_OK;
 }
 
 template <int P>
-int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, int n1, int n2, RsOut o) {
+int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* g1, int n1, const int32_t* g2, int n2, RsOut o) {
     const int stride = (n1 + n2) | 1;
     const int waves = 2;
     const size_t lds = (size_t)waves * 32 * stride * 4 + (size_t)(n1 + n2) * 4;
@@ -1338,7 +1338,7 @@ int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_pair_kernel<P>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_LAUNCH(ctx, "ranksum_pair_kernel", (ranksum_pair_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
-              s, gsel, n1, n2, stride, o);
+              s, g1, g2, n1, n2, stride, o);
     SD_LAUNCH(ctx, "ranksum_finish_kernel", ranksum_finish_kernel, dim3((unsigned)sd_ceil_div(n, 256)), dim3(256), 0, n,
               o.p, o.z);
     return SDICE_OK;
@@ -1346,7 +1346,7 @@ int launch_pair(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
 
 // 16-bit-key lane-pair kernel, then the sorting wave kernel over the rows it marked (non 3-decimal values)
 template <int P>
-int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* gsel, const int32_t* g1, int n1,
+int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32_t* g1, int n1,
                  const int32_t* g2, int n2, RsOut o) {
     const int stride = RSQ_STRIDE;                         // u16 units (n1, n2 <= 64)
     const int waves = 4;
@@ -1358,7 +1358,7 @@ int launch_pairq(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int3
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_pairq_kernel<P>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_LAUNCH(ctx, "ranksum_pairq_kernel", (ranksum_pairq_kernel<P>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
-              s, gsel, n1, n2, stride, o);
+              s, g1, g2, n1, n2, stride, o);
     {   // rows marked RS_REDO (a value that is not float32(k/1000)): the float sorting kernel, marked rows only
         const int ww = 4;
         const size_t lds_w = (size_t)ww * (2 * 64 + 40) * 4;
@@ -1403,28 +1403,25 @@ extern "C" int sdice_ranksum_dev(sdice_ctx* ctx, int64_t n, int32_t s, const flo
     const bool lane_ok = n1 <= 64 && n2 <= 64;
     SD_ARG((variant != 1 && variant != 4) || lane_ok, "lane variants need n1, n2 <= 64");
     if ((variant == 0 && lane_ok) || variant == 1 || variant == 4) {
-        int32_t* gsel = (int32_t*)ctx->arena.alloc((size_t)(n1 + n2) * 4);
-        if (!gsel) return SDICE_ERR_NOMEM;
-        SD_HIP(hipMemcpyAsync(gsel, d_g1, (size_t)n1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        SD_HIP(hipMemcpyAsync(gsel + n1, d_g2, (size_t)n2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        // (the kernels read the two index lists themselves: two device-to-device copies into one list cost 9 us per call)
         const int big = n1 > n2 ? n1 : n2;
         if (variant == 0 && big > 16 && n1 <= 63) {     // auto, groups of 17..64 (group 1 <= 63: its sentinel slot): the lane-pair kernel on 16-bit keys
-            if (big <= 32) return launch_pairq<32>(ctx, d_ps, n, s, gsel, d_g1, n1, d_g2, n2, o);
-            return launch_pairq<64>(ctx, d_ps, n, s, gsel, d_g1, n1, d_g2, n2, o);
+            if (big <= 32) return launch_pairq<32>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            return launch_pairq<64>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
         }
         if (variant != 1) {      // groups <= 16 and variant 4: the float lane-pair kernel (1.45x the lane kernel at 50 v 50)
             switch (next_pow2(big < 8 ? 8 : big)) {
-                case 8: return launch_pair<8>(ctx, d_ps, n, s, gsel, n1, n2, o);
-                case 16: return launch_pair<16>(ctx, d_ps, n, s, gsel, n1, n2, o);
-                case 32: return launch_pair<32>(ctx, d_ps, n, s, gsel, n1, n2, o);
-                default: return launch_pair<64>(ctx, d_ps, n, s, gsel, n1, n2, o);
+                case 8: return launch_pair<8>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+                case 16: return launch_pair<16>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+                case 32: return launch_pair<32>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+                default: return launch_pair<64>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
             }
         }
         switch (next_pow2(big < 8 ? 8 : big)) {
-            case 8: return launch_lane<8>(ctx, d_ps, n, s, gsel, n1, n2, o);
-            case 16: return launch_lane<16>(ctx, d_ps, n, s, gsel, n1, n2, o);
-            case 32: return launch_lane<32>(ctx, d_ps, n, s, gsel, n1, n2, o);
-            default: return launch_lane<64>(ctx, d_ps, n, s, gsel, n1, n2, o);
+            case 8: return launch_lane<8>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            case 16: return launch_lane<16>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            case 32: return launch_lane<32>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
+            default: return launch_lane<64>(ctx, d_ps, n, s, d_g1, n1, d_g2, n2, o);
         }
     }
     const int big = n1 > n2 ? n1 : n2;
