@@ -538,6 +538,15 @@ def test_fisher_pairs_vs_scipy(ctx, n, s, mean):
     want = O.fisher_pairs(incl, excl)
     got = ctx.fisher_pairs(incl, excl)
     np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
+    # a log-factorial table of 64 entries: tables with a larger total leave the pair kernel as markers and are finished
+    # by fisher_beyond_table_kernel (rows with such tables only; here some, all or -- margins of zero -- none of a row's pairs)
+    ctx.set_param("fisher.table_max", 64)
+    try:
+        got2 = ctx.fisher_pairs(incl, excl)
+    finally:
+        ctx.set_param("fisher.table_max", 1 << 20)
+    assert (got2 >= 0).all()
+    np.testing.assert_allclose(got2, want, rtol=P_RTOL_TIGHT, atol=0)
 
 
 def test_fisher_pairs_long_walks_and_sparse_rows(ctx):
