@@ -810,6 +810,8 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
         vf = {"peak": F64_WAVE_INSTS_SPEC, "unit": "wave64 VALU instructions/s (all VALU, f64 and not)",
               "peak_measured_fma_loop": F64_WAVE_INSTS_PER_S}
         try:
+            if not all(hasattr(wl, a) for a in ("d_counts", "d_excl", "d_p")):
+                raise AttributeError("lane-step counts are taken on the unsharded workload (N = 1)")
             ctx.set_param("fisher.count_steps", 1)
             ctx.fisher_pairs_dev(wl.d_counts, wl.d_excl, wl.d_p)
             useful, issued = ctx.fisher_step_stats()
@@ -819,7 +821,8 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
                        "valu_per_step": 10, "step_valu_rate": issued / 64 * 10 / (avg_ms * 1e-3),
                        "step_valu_frac_of_peak": issued / 64 * 10 / (avg_ms * 1e-3) / F64_WAVE_INSTS_SPEC})
         except Exception as e:                                  # noqa: BLE001 (a measurement aid must not fail the line)
-            vf["lane_steps_error"] = str(e)
+            ctx.set_param("fisher.count_steps", 0)
+            vf["lane_steps_note"] = str(e)
         try:
             with open(os.path.join(REPO, "profiles", "pairwise_valu.json")) as fh:
                 pv = json.load(fh)
