@@ -276,53 +276,6 @@ __device__ __forceinline__ void wave_bitonic(uint64_t (&key)[K], uint32_t (&val)
     }
 }
 
-// the same network in the composite order (key, val): for splitters, which must be ordered among equal keys too
-template <int K>
-__device__ __forceinline__ void wave_bitonic_kv(uint64_t (&key)[K], uint32_t (&val)[K], const int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64 * K; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j >= 1; j >>= 1) {
-            if (j >= K) {
-                const int lm = j / K;
-                const bool lower = (lane & lm) == 0;
-                const bool up = k2 >= 64 * K ? true : (lane & (k2 / K)) == 0;
-                const bool keep_min = lower == up;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint64_t o = shfl_xor_u64(key[k], lm);
-                    const uint32_t ov = (uint32_t)__shfl_xor((int)val[k], lm);
-                    const bool o_less = o < key[k] || (o == key[k] && ov < val[k]);
-                    const bool o_more = o > key[k] || (o == key[k] && ov > val[k]);
-                    const bool take = keep_min ? o_less : o_more;
-                    key[k] = take ? o : key[k];
-                    val[k] = take ? ov : val[k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int kp = k ^ j;
-                    if (kp > k) {
-                        bool up;
-                        if (k2 < K) up = (k & k2) == 0;
-                        else if (k2 >= 64 * K) up = true;
-                        else up = (lane & (k2 / K)) == 0;
-                        const bool p_less = key[kp] < key[k] || (key[kp] == key[k] && val[kp] < val[k]);
-                        const bool p_more = key[kp] > key[k] || (key[kp] == key[k] && val[kp] > val[k]);
-                        const bool sw = up ? p_less : p_more;
-                        const uint64_t tk = key[k];
-                        const uint32_t tv = val[k];
-                        key[k] = sw ? key[kp] : tk;
-                        val[k] = sw ? val[kp] : tv;
-                        key[kp] = sw ? tk : key[kp];
-                        val[kp] = sw ? tv : val[kp];
-                    }
-                }
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ uint64_t raw_bits(uint64_t key, int64_t rank1, int64_t m) {
     // p_(i) / (i / m), the arithmetic of the generic path (bh.hip bh_raw_kernel)
     const double ps = __longlong_as_double((long long)key);
