@@ -99,6 +99,13 @@ struct Walk {
     __device__ __forceinline__ bool tail_negligible() const {
         return eP == 0 && P <= Q && N + N < D && P < 1e-13 * (Q + S);
     }
+    // may TRIP more steps be taken without rescale()?  A step multiplies P and Q by less than 2^62 (a trip: 2^496) and
+    // S <= 2^31 Q: yes while Q and P are below 2^490 (2^490 * 2^496 * 2^31 < 2^1023) -- with counts in the thousands Q
+    // grows by ~2^20 per step and the answer is yes; a lane with eP > 0 keeps its per-trip invariant only through
+    // rescale().  Wave-uniform answer.
+    __device__ __forceinline__ bool rescale_due() const {
+        return __ballot(Q > 0x1p490 || P > 0x1p490 || eP != 0) != 0ull;
+    }
     __device__ __forceinline__ void rescale() {
         const int e = 1 - __builtin_amdgcn_frexp_exp(Q);        // Q >= 1: back into [1, 2)
         Q = __builtin_ldexp(Q, e); S = __builtin_ldexp(S, e); P = __builtin_ldexp(P, e);
@@ -351,7 +358,9 @@ fisher_pairs_kernel(const int32_t* __restrict__ incl, const int64_t* __restrict_
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {
                 w.step(ok);
-                if (k % Walk::TRIP == Walk::TRIP - 1 && k + 1 < UNROLL) { w.rescale(); ok = w.eP == 0; }
+                // between the halves of a long trip the scaling is only due when some lane's products have left the first
+                // half of the exponent range (wave-uniform test: 3 instructions instead of ~14)
+                if (k % Walk::TRIP == Walk::TRIP - 1 && k + 1 < UNROLL && w.rescale_due()) { w.rescale(); ok = w.eP == 0; }
             }
             w.rescale();
             const bool fin = phase != 0 && (w.at_end() || w.tail_negligible());

@@ -549,6 +549,24 @@ def test_fisher_pairs_vs_scipy(ctx, n, s, mean):
     np.testing.assert_allclose(got2, want, rtol=P_RTOL_TIGHT, atol=0)
 
 
+def test_fisher_pairs_walks_across_the_mode_with_tiny_p(ctx):
+    """pairs whose observed table lies hundreds of standard deviations from the mode: the up-walk crosses the mode with
+    the numerator product outgrowing the denominator by more than 2^500 (the exponent count of the walk, the scaling
+    between the halves of a trip), p-values down to ~1e-267; every lane of the wave busy with a different mix"""
+    rng = np.random.default_rng(4242)
+    s = 12
+    incl = np.empty((6, s), np.int32)
+    excl = np.empty((6, s), np.int64)
+    for r in range(6):
+        hi = rng.random(s) < 0.5
+        incl[r] = np.where(hi, rng.integers(300, 460, s), rng.integers(0, 12, s))
+        excl[r] = np.where(hi, rng.integers(0, 12, s), rng.integers(300, 460, s))
+    want = O.fisher_pairs(incl, excl)
+    got = ctx.fisher_pairs(incl, excl)
+    assert (want < 1e-250).any() and (want > 1e-3).any() and (want >= 1e-280).all()   # (scipy's own range: DESIGN.md section 7)
+    np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
+
+
 def test_fisher_pairs_long_walks_and_sparse_rows(ctx):
     """the pair kernel's state machine on walks of hundreds of steps (counts in the thousands: the products P, Q, S are
     rescaled every few steps, the negligible-tail cut ends the walks) and on sparse rows (most pairs have a zero margin
