@@ -107,8 +107,11 @@ struct Walk {
         return __ballot(Q > 0x1p490 || P > 0x1p490 || eP != 0) != 0ull;
     }
     __device__ __forceinline__ void rescale() {
-        const int e = 1 - __builtin_amdgcn_frexp_exp(Q);        // Q >= 1: back into [1, 2)
-        Q = __builtin_ldexp(Q, e); S = __builtin_ldexp(S, e); P = __builtin_ldexp(P, e);
+        // Q >= 1 (a normal number): back into [1, 2) by the power of two whose exponent field mirrors Q's -- three
+        // full-rate multiplications (v_frexp_exp / v_ldexp_f64 are quarter-rate: the same scaling cost 20 issue slots)
+        const unsigned ef = ((unsigned)__double2hiint(Q) >> 20) & 0x7ffu;
+        const double sc = __hiloint2double((int)((2046u - ef) << 20), 0);
+        Q *= sc; S *= sc; P *= sc;
         const bool up = P > 0x1p500, dn = eP > 0 && P < 0x1p-3;
         if (__ballot(up || dn) != 0ull) {                       // (wave-uniform: a ratio beyond 2^500 is a rare guest)
             P = __builtin_ldexp(P, up ? -500 : dn ? 500 : 0);
