@@ -52,8 +52,9 @@ struct BhsArgs {
     uint16_t* bid_cm;       // [segs][m] bucket of each value
     uint64_t* bmin;         // [segs][B]
     uint64_t* sfx;          // [segs][B] minimum over the LATER buckets
-    unsigned* big_count;    // buckets of more than 256 values: work list of the second bucket kernel
-    int64_t* big_list;      // [segs * B]
+    unsigned* big_count;    // [8] buckets of more than 256 values: work lists of the second bucket kernel, one per XCD
+    int64_t* big_list;      // [8][big_region]: list x holds buckets of the segments with seg mod 8 == x
+    int64_t big_region;
     int reg_cap;            // buckets beyond this many values take the in-HBM path (1024; lower in tests)
 };
 
@@ -427,18 +428,23 @@ __global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int blocks_p
     if (r.n_b <= 256 && r.n_b <= a.reg_cap) {
         bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
     } else if (lane == 0) {
-        const unsigned slot = atomicAdd(a.big_count, 1u);
-        a.big_list[slot] = g;
+        // (one list per XCD: the big kernel's workgroups keep to the list of "their" segments, so that the scattered
+        //  results of a segment still meet in ONE L2 -- a single list in arrival order spread them over all eight)
+        const int x = (int)(seg_x & 7);
+        const unsigned slot = atomicAdd(&a.big_count[x], 1u);
+        a.big_list[(int64_t)x * a.big_region + slot] = g;
     }
 }
 
 __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
     const int lane = threadIdx.x & 63;
-    const unsigned n_big = *a.big_count;
-    const unsigned waves = gridDim.x * 4;
+    const int x = (int)(blockIdx.x & 7);
+    const unsigned n_big = a.big_count[x];
+    const unsigned waves = (gridDim.x >> 3) * 4;
+    const int64_t* list = a.big_list + (int64_t)x * a.big_region;
 #pragma nounroll
-    for (unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_big; w += waves) {
-        const BucketRef r = bucket_ref(a, a.big_list[w]);
+    for (unsigned w = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6); w < n_big; w += waves) {
+        const BucketRef r = bucket_ref(a, list[w]);
         if (r.n_b > a.reg_cap && !r.pd) bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
         else if (r.n_b <= 256) bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
         else if (r.n_b <= 512) bucket_in_regs<8>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
@@ -1028,8 +1034,9 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     a.start = (unsigned*)A.alloc((size_t)segs * (size_t)(B + 1) * 4);
     a.q_cm = (uint64_t*)A.alloc(vals * 8);
     a.bid_cm = (uint16_t*)A.alloc(vals * 2);
-    a.big_list = (int64_t*)A.alloc(sb * 8);
-    a.big_count = (unsigned*)A.alloc(8);
+    a.big_region = sd_ceil_div(segs, (int64_t)8) * B;
+    a.big_list = (int64_t*)A.alloc((size_t)a.big_region * 8 * 8);
+    a.big_count = (unsigned*)A.alloc(32);
     a.keyS = B > 1 ? (uint64_t*)A.alloc(vals * 8) : nullptr;
     a.idxS = B > 1 ? (uint32_t*)A.alloc(vals * 4) : nullptr;
     if (!a.spl_k || !a.bmin || !a.sfx || !a.spl_i || !a.gcount || !a.cursor || !a.start || !a.q_cm || !a.bid_cm || !a.big_list || !a.big_count ||
@@ -1061,13 +1068,14 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     }
     const int64_t n_buckets = segs * B;
     SD_ARG(sd_ceil_div(n_buckets, (int64_t)4) < ((int64_t)1 << 31), "bh: too many buckets");
-    SD_HIP(hipMemsetAsync(a.big_count, 0, 8, ctx->stream));
+    SD_HIP(hipMemsetAsync(a.big_count, 0, 32, ctx->stream));
     const int blocks_per_seg = (int)sd_ceil_div((int64_t)B, (int64_t)4);
     const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * blocks_per_seg;
     SD_ARG(bucket_blocks < ((int64_t)1 << 31), "bh: too many buckets");
     SD_LAUNCH(ctx, "bhs_bucket_kernel", bhs_bucket_kernel, dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
-    SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel,
-              dim3((unsigned)std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4)), dim3(256), 0, a);
+    // (a multiple of 8 workgroups, at least 8: workgroup w serves the list of XCD w mod 8)
+    const int64_t big_blocks = std::max<int64_t>(8, sd_ceil_div(std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4), (int64_t)8) * 8);
+    SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel, dim3((unsigned)big_blocks), dim3(256), 0, a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);
     const int64_t gx = sd_ceil_div(m, (int64_t)32);
     for (int64_t c0 = 0; c0 < segs; c0 += (int64_t)65535 * 32) {
