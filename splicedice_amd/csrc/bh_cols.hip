@@ -137,20 +137,25 @@ __global__ void __launch_bounds__(256) bhs_sample_kernel(BhsArgs a) {
 
 // ---------------------------------------------------------------- 2. / 4. count and scatter
 template <bool SCATTER>
-__global__ void __launch_bounds__(TILE_T) bhs_tile_kernel(BhsArgs a) {
+__global__ void __launch_bounds__(TILE_T) bhs_tile_kernel(BhsArgs a, int tiles) {
     extern __shared__ uint64_t smem_t[];
     uint64_t* sk = smem_t;                                            // [B]
     uint32_t* si = reinterpret_cast<uint32_t*>(sk + a.B);             // [B]
     unsigned* hist = reinterpret_cast<unsigned*>(si + a.B);           // [B]
     unsigned* base = hist + a.B;                                      // [B]
-    const int seg = blockIdx.y, tid = threadIdx.x;
+    // 1-D grid, workgroups dealt round-robin over the 8 XCDs: all tiles of a segment go to ONE XCD (segment mod 8), so
+    // that the runs a bucket receives from the segment's tiles -- their ends share cache lines -- meet in one L2
+    const int64_t kk = (int64_t)(blockIdx.x >> 3);
+    const int64_t seg64 = (kk / tiles) * 8 + (blockIdx.x & 7);
+    if (seg64 >= a.segs) return;
+    const int seg = (int)seg64, tile_x = (int)(kk % tiles), tid = threadIdx.x;
     const int ns = a.B - 1;
     for (int b = tid; b < a.B; b += TILE_T) {
         hist[b] = 0;
         if (b < ns) { sk[b] = a.spl_k[(int64_t)seg * a.B + b]; si[b] = a.spl_i[(int64_t)seg * a.B + b]; }
     }
     __syncthreads();
-    const int64_t e0 = (int64_t)blockIdx.x * TILE;
+    const int64_t e0 = (int64_t)tile_x * TILE;
     const double* p = a.p_cm + (int64_t)seg * a.m;
     uint64_t key[TILE_E];
     int bkt[TILE_E];
@@ -1050,21 +1055,11 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
         SD_LAUNCH(ctx, "bhs_sample_kernel", bhs_sample_kernel, dim3((unsigned)segs), dim3(256), lds_s, a);
         const size_t lds_t = (size_t)B * 20;
         const int64_t tiles = sd_ceil_div(m, (int64_t)TILE);
-        // blockIdx.y is limited to 65535: segments go in slices
-        for (int64_t s0 = 0; s0 < segs; s0 += 65535) {
-            BhsArgs b = a;
-            const int64_t sc = std::min<int64_t>(65535, segs - s0);
-            b.p_cm += s0 * m; b.spl_k += s0 * B; b.spl_i += s0 * B; b.gcount += s0 * B;
-            SD_LAUNCH(ctx, "bhs_count_kernel", (bhs_tile_kernel<false>), dim3((unsigned)tiles, (unsigned)sc), dim3(TILE_T), lds_t, b);
-        }
+        const int64_t tile_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * tiles;
+        SD_ARG(tile_blocks < ((int64_t)1 << 31), "bh: too many tiles");
+        SD_LAUNCH(ctx, "bhs_count_kernel", (bhs_tile_kernel<false>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
         SD_LAUNCH(ctx, "bhs_scan_kernel", bhs_scan_kernel, dim3((unsigned)segs), dim3(256), 0, a);
-        for (int64_t s0 = 0; s0 < segs; s0 += 65535) {
-            BhsArgs b = a;
-            const int64_t sc = std::min<int64_t>(65535, segs - s0);
-            b.p_cm += s0 * m; b.spl_k += s0 * B; b.spl_i += s0 * B; b.cursor += s0 * B;
-            b.keyS += s0 * m; b.idxS += s0 * m;
-            SD_LAUNCH(ctx, "bhs_scatter_kernel", (bhs_tile_kernel<true>), dim3((unsigned)tiles, (unsigned)sc), dim3(TILE_T), lds_t, b);
-        }
+        SD_LAUNCH(ctx, "bhs_scatter_kernel", (bhs_tile_kernel<true>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
     }
     const int64_t n_buckets = segs * B;
     SD_ARG(sd_ceil_div(n_buckets, (int64_t)4) < ((int64_t)1 << 31), "bh: too many buckets");
