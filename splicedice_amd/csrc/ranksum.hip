@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) ranksum_lane_kernel(const float* __restri
                                                            int stride, RsOut o, int ablate) {
     extern __shared__ float smemf[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: row indices and offsets stay scalar)
     const int waves_per_block = blockDim.x >> 6;
     float* tile = smemf + (size_t)wave * 64 * stride;
     const int nsel = n1 + n2;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restri
                                                            int stride, RsOut o) {
     extern __shared__ float smemp[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: row indices and offsets stay scalar)
     const int waves_per_block = blockDim.x >> 6;
     float* tile = smemp + (size_t)wave * 32 * stride;
     const int nsel = n1 + n2;
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     extern __shared__ float smemq[];
     constexpr int NR = P / 2;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: row indices and offsets stay scalar)
     const int waves_per_block = blockDim.x >> 6;
     const int nsel = n1 + n2;
     int* selL = reinterpret_cast<int*>(smemq);                          // [nsel]
@@ -879,7 +879,7 @@ __global__ void __launch_bounds__(256) ranksum_wave_kernel(const float* __restri
     extern __shared__ __align__(16) float smemw[];
     constexpr int N = 64 * E;
     constexpr int WSTRIDE = 2 * N + 40;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     float* SA = smemw + (size_t)wave * WSTRIDE;
     float* SB = SA + N;
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
     // are taken, and 4 KB less per wave lets a fifth wave per SIMD in (the kernel is latency bound)
     constexpr bool H_ALIAS = 2 * N >= RS_BINS;
     constexpr int WSTRIDE = 2 * N + 40 + (H_ALIAS ? 0 : RS_BINS) + 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     float* SA = smemc + (size_t)wave * WSTRIDE;
     float* SB = SA + N;
