@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int blocks_p
     const int lane = threadIdx.x & 63;
     const int64_t k = (int64_t)(blockIdx.x >> 3);
     const int64_t seg_x = (k / blocks_per_seg) * 8 + (blockIdx.x & 7);
-    const int b_x = (int)(k % blocks_per_seg) * 4 + (int)(threadIdx.x >> 6);
+    const int b_x = (int)(k % blocks_per_seg) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the bucket's addresses stay in SGPRs)
     if (seg_x >= a.segs || b_x >= a.B) return;
     const int64_t g = seg_x * a.B + b_x;
     const BucketRef r = bucket_ref(a, g);
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
     const unsigned waves = (gridDim.x >> 3) * 4;
     const int64_t* list = a.big_list + (int64_t)x * a.big_region;
 #pragma nounroll
-    for (unsigned w = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6); w < n_big; w += waves) {
+    for (unsigned w = (blockIdx.x >> 3) * 4 + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); w < n_big; w += waves) {
         const BucketRef r = bucket_ref(a, list[w]);
         if (r.n_b > a.reg_cap && !r.pd) bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
         else if (r.n_b <= 256) bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);

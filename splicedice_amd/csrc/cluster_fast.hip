@@ -422,7 +422,7 @@ __device__ __forceinline__ void ss_sort_sub(const uint64_t* kb, const unsigned s
 __device__ __forceinline__ bool lds_sample_sort(uint64_t* kb, int count, int t) {
     __shared__ unsigned s_cnt[SS_NB], s_base[SS_NB + 1], s_max;
     __shared__ uint64_t s_spl[SS_NB];
-    const int lane = t & 63, w = t >> 6;
+    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     uint64_t* smp = kb + count;
     const int ns = count <= 2048 ? 128 : 256;                           // 8 or 16 samples per sub-bucket
     const int per = ns / SS_NB;
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(SORT_T, 8) bucket_sort_kernel(FastArgs a) {   
     __shared__ unsigned long long wsum[SORT_WAVES];
     __shared__ uint32_t red[5][SORT_WAVES];
     __shared__ uint32_t s_dup;
-    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     if (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW)) return;      // uniform: written by the previous kernel
     const int count = (int)a.cursor[b];
     // first row of this bucket = number of keys in the buckets before it
@@ -758,7 +758,7 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     uint16_t* rid = reinterpret_cast<uint16_t*>(wR + W);
     uint16_t* pos = rid + W;
     int32_t* stage = reinterpret_cast<int32_t*>(u_mem);
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = (int)a.n;
     const int n_tiles = (n + T - 1) / T;
     const int tile = blockIdx.x;

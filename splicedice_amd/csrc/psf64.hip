@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(PF_WAVES * 64) ps_f64_kernel(int64_t n_out, in
                                                                 const int64_t* __restrict__ row_ptr,
                                                                 const int32_t* __restrict__ col, double* __restrict__ ps) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * PF_WAVES + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * PF_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t stride = (int64_t)gridDim.x * PF_WAVES;
     for (int64_t row = wave0; row < n_out; row += stride) {
         const int64_t k0 = row_ptr[row], k1 = row_ptr[row + 1];

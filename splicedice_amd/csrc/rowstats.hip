@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) rowstats_kernel(const T* __restrict__ dat
                                                        const int32_t* __restrict__ idx, int K, T* __restrict__ mean_out,
                                                        T* __restrict__ std_out, int32_t* __restrict__ nan_out) {
     extern __shared__ __align__(16) unsigned char smem_rs[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
     const size_t per_wave = ((size_t)K * sizeof(T) + 15) / 16 * 16 + 24 * sizeof(T) + 24 * sizeof(int);
     unsigned char* base = smem_rs + (size_t)wave * per_wave;
     T* C = reinterpret_cast<T*>(base);
