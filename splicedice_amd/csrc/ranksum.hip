@@ -1068,7 +1068,7 @@ template <int E>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4 ? 6 : E <= 8 ? 5 : 3, 8))) ranksum_count_kernel(const float* __restrict__ ps, int64_t n, int s,
                                                             const int32_t* __restrict__ g1, int n1,
                                                             const int32_t* __restrict__ g2, int n2, int ch,
-                                                            RsOut o) {
+                                                            int abl /* timing experiments: 1 = always the ordered compaction */, RsOut o) {
     extern __shared__ __align__(16) float smemc[];
     constexpr int N = 64 * E;
     // for E >= 8 the histogram lives in the SA | SB area (1024 words): the compacted values are dead once the two pairwise sums
@@ -1135,16 +1135,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E <= 4
         }
         SD_WAVE_SYNC();          // the previous row's readers are done with the wave's LDS
         int nv1 = 0, nv2 = 0;
+        bool hole = false;       // a selected value that is NaN
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool v1 = (kk[e] & 0xffffu) != 0u;
-            const unsigned long long m1 = __ballot(v1);
-            if (v1) SA[lanes_below(m1, nv1)] = x[e];
-            nv1 += __popcll(m1);
-            const bool v2 = (kk[e] >> 16) != 0u;
-            const unsigned long long m2 = __ballot(v2);
-            if (v2) SB[lanes_below(m2, nv2)] = y[e];
-            nv2 += __popcll(m2);
+        for (int e = 0; e < E; ++e)
+            hole = hole || (idx1[e] >= 0 && (kk[e] & 0xffffu) == 0u) || (idx2[e] >= 0 && (kk[e] >> 16) == 0u);
+        if (!(abl & 1) && __ballot(hole) == 0ull) {
+            // no NaN among the row's selected values (nearly every row): the compacted order IS the selection order --
+            // plain stores, none of the 2 E ballots, prefix counts and popcounts of the ordered compaction
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (idx1[e] >= 0) SA[e * 64 + lane] = x[e];
+                if (idx2[e] >= 0) SB[e * 64 + lane] = y[e];
+            }
+            nv1 = n1; nv2 = n2;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool v1 = (kk[e] & 0xffffu) != 0u;
+                const unsigned long long m1 = __ballot(v1);
+                if (v1) SA[lanes_below(m1, nv1)] = x[e];
+                nv1 += __popcll(m1);
+                const bool v2 = (kk[e] >> 16) != 0u;
+                const unsigned long long m2 = __ballot(v2);
+                if (v2) SB[lanes_below(m2, nv2)] = y[e];
+                nv2 += __popcll(m2);
+            }
         }
         // clear the histogram: 16 words per lane (when it shares the SA | SB area: after the sums)
         if (!H_ALIAS) {
@@ -1300,7 +1315,7 @@ int launch_wave(sdice_ctx* ctx, const float* d_ps, int64_t n, int s, const int32
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ranksum_count_kernel<E>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         SD_LAUNCH(ctx, "ranksum_count_kernel", (ranksum_count_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds_c,
-                  d_ps, n, s, g1, n1, g2, n2, ch, o);
+                  d_ps, n, s, g1, n1, g2, n2, ch, (int)ctx->param("ranksum.ablate", 0), o);
     }
     SD_LAUNCH(ctx, "ranksum_wave_kernel", (ranksum_wave_kernel<E>), dim3((unsigned)blocks), dim3(waves * 64), lds, d_ps, n,
               s, g1, n1, g2, n2, ch, counting ? 1 : 0, o);
