@@ -904,20 +904,34 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_v3_kernel(PsArgs a) {
         const int items = nr * V;
         int ri = tid / V, c = tid - ri * V;
         const int dr = T / V, dc = T - dr * V;
+        // the outputs are addressed as (tile base: scalar) + (32-bit element offset inside the tile: the host keeps a tile
+        // below 2^30 elements), and the offsets of successive items follow by additions: no 64-bit multiply-add, no
+        // 32-bit multiplications (quarter-rate) per item -- the kernel runs at 3/4 of the VALU issue rate
+        PsArgs b = a;
+        {
+            const int64_t tile_base = (int64_t)r0 * a.s + c0;
+            if (WPS) b.ps = a.ps + tile_base;
+            if (WEXCL) b.excl = a.excl + tile_base;
+        }
+        unsigned o32 = (unsigned)ri * (unsigned)a.s + (unsigned)(c * VEC);
+        const unsigned d_o = (unsigned)dr * (unsigned)a.s + (unsigned)(dc * VEC), wrap_o = (unsigned)a.s - (unsigned)(V * VEC);
+        int own_off = (a.halo + ri) * rowb;
+        const int d_own = dr * rowb;
+        // (degree + 1) * (largest count of the tile) < 2^24  <=>  degree + 1 <= deg_lim
+        const unsigned deg_lim = tile_cmax ? 0xFFFFFFu / tile_cmax : 0xFFFFFFFFu;
         for (int it = tid; it < items; it += T) {
             const int k0 = rpL[ri], k1 = rpL[ri + 1];
-            const int64_t o = (int64_t)(r0 + ri) * a.s + c0 + c * VEC;
-            const int own_off = (a.halo + ri) * rowb;
+            const int64_t o = (int64_t)(uint64_t)o32;
             bool done = false;
             const unsigned deg = (unsigned)(k1 - k0);
-            if (fast_tile && deg < 254u && __umul24(deg + 1u, tile_cmax) <= 0xFFFFFFu)
-                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
-                              : ps_item_fast<VEC, WEXCL, WPS, true, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
+            if (fast_tile && deg < 254u && deg + 1u <= deg_lim)
+                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, 0>(b, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
+                              : ps_item_fast<VEC, WEXCL, WPS, true, Q3, 0>(b, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
             if (!done)
-                ps_item_slow<VEC, WEXCL, WPS, Q3, 0>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
+                ps_item_slow<VEC, WEXCL, WPS, Q3, 0>(b, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
                                                      own_off, o, wbase);
-            c += dc; ri += dr;
-            if (c >= V) { c -= V; ri += 1; }
+            c += dc; ri += dr; o32 += d_o; own_off += d_own;
+            if (c >= V) { c -= V; ri += 1; o32 += wrap_o; own_off += rowb; }
         }
     }
 }
@@ -1040,6 +1054,7 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     const bool pow2chunk = cw == s || (cw / 4 <= 64 && 64 % (cw / 4) == 0);
     int kern = (int)ctx->param("ps.dma", 0);
     if (vec != 4 || abl != 0 || !pow2chunk || kern < 0 || kern > 2) kern = 2;
+    if ((int64_t)s * 2048 >= ((int64_t)1 << 30)) kern = 2;       // (the newer kernels address a tile's outputs by 32-bit offsets)
     const bool dma = kern == 1;
     const bool newk = kern != 2;
     int64_t lds = ctx->param("ps.lds_bytes", 80 * 1024);   // two workgroups per CU (160 KiB LDS)
