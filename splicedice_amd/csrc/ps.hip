@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_v3_kernel(PsArgs a) {
             const int j = jv[k];
             const bool in = (unsigned)(j - slo) < (unsigned)wrows;
             outside = outside || !in;
-            colL[kk] = in ? (j - wbase) * rowb : -1 - j;
+            colL[kk] = in ? (int)__umul24((unsigned)(j - wbase), (unsigned)rowb) : -1 - j;      // (window rows < 2^12, row bytes < 2^18: full-rate 24-bit multiply)
         }
     }
     if (tid <= nr) rpL[tid] = rp_mine[0] - (int)kbase;
