@@ -142,6 +142,30 @@ __device__ __forceinline__ v2f div_small_ints2(v2f a, v2f t) {
     return __builtin_elementwise_fma(rem, r, q);
 }
 
+// k = round-half-even(x * 1000) for a float32 x in [0, 1] (NaN stays NaN), as the decimal formatter of '%.3f' rounds the
+// EXACT value of x -- without float64 (v_cvt_f64_f32, v_rndne_f64, v_cvt_f32_f64 are quarter-rate: 13 issue slots per
+// value): p = fl(x * 1000) and e = fma(x, 1000, -p) give the exact product p + e (|e| <= ulp(p) / 2 <= 2^-15); k0 =
+// rint(p) is the answer unless p sits exactly on a half integer and e is not zero -- then the true value lies on e's
+// side of it.  (|p - k0| < 1/2 implies |p - k0| <= 1/2 - ulp(p), so e cannot carry the sum across a half integer.)
+__device__ __forceinline__ v2f thousandths2(v2f x) {
+    const v2f th = {1000.0f, 1000.0f};
+    const v2f p = x * th;
+    const v2f e = __builtin_elementwise_fma(x, th, -p);
+    v2f k0, k;
+    k0.x = __builtin_rintf(p.x); k0.y = __builtin_rintf(p.y);
+    const v2f r = p - k0;
+    k.x = (__builtin_fabsf(r.x) == 0.5f && e.x != 0.0f) ? p.x + __builtin_copysignf(0.5f, e.x) : k0.x;
+    k.y = (__builtin_fabsf(r.y) == 0.5f && e.y != 0.0f) ? p.y + __builtin_copysignf(0.5f, e.y) : k0.y;
+    return k;
+}
+// float32(k / 1000.0) for an integer-valued k in [0, 1000]: k * 0.001f and one residual step give the correctly rounded
+// quotient for all 1001 keys (exhaustive test in rational arithmetic: test_ps_of_key_formula_reproduces_the_table)
+__device__ __forceinline__ v2f key_over_1000(v2f k) {
+    const v2f m = {0.001f, 0.001f}, th = {1000.0f, 1000.0f};
+    const v2f q = k * m;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-q, th, k), m, q);
+}
+
 // Fast item: every neighbour offset comes from the LDS stage and lies inside the staged window,
 // the tile's bound keeps incl + excl < 2^24 -> 32-bit sums, float32 quotient.  Returns false
 // (nothing stored) as soon as a neighbour is outside the window; the caller then runs ps_item_slow.
@@ -188,13 +212,7 @@ __device__ __forceinline__ bool ps_item_fast(const PsArgs& a, const char* tileB,
                 const v2f num = {(float)i0, (float)i1};
                 const v2f den = {(float)(i0 + acc[q]), (float)(i1 + acc[q + 1])};
                 v2f ps2 = div_small_ints2(num, den);
-                if (Q3) {
-                    // fused K4: k = rint(ps * 1000) (exact product in float64, half-even as the formatter),
-                    // float32(k / 1000.0) == correctly rounded float32 quotient of the two small integers
-                    const v2f k2 = {(float)rint((double)ps2.x * 1000.0), (float)rint((double)ps2.y * 1000.0)};
-                    const v2f th = {1000.0f, 1000.0f};
-                    ps2 = div_small_ints2(k2, th);
-                }
+                if (Q3) ps2 = key_over_1000(thousandths2(ps2));     // fused K4: float32(f'{ps:.3f}')
                 o[q] = ps2.x; o[q + 1] = ps2.y;
             }
         } else {

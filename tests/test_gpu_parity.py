@@ -386,6 +386,39 @@ def test_ps_fused_quantise(ctx, n, s, big):
     assert np.array_equal(fused, want, equal_nan=True)
 
 
+def test_ps_fused_quantise_on_rounding_boundaries(ctx):
+    """the fused '.3f' round trip works in float32 (exact product by fma, half integers decided by the residual): PS values
+    k/d that sit exactly on a rounding boundary (d = 16, 32, ...: x * 1000 is a half integer), next to one (d = 2000, 4000,
+    ...: float32(a/d) * 1000 rounds to a half integer in float32 but the exact product lies beside it) and everything in
+    between, against the float64 restatement and the separate quantise kernel"""
+    S = 128
+    dens = [16, 32, 64, 80, 160, 625, 1600, 2000, 3125, 4000, 6000, 14000, 16000]
+    pairs = []                                             # (a, b): PS = a / (a + b) for one row, b / (a + b) for its partner
+    for d in dens:
+        pairs += [(a, d - a) for a in range(d + 1)]
+    n_pairs = -(-len(pairs) // S)
+    pairs += [(1, 1)] * (n_pairs * S - len(pairs))
+    ab = np.array(pairs, dtype=np.int32).reshape(n_pairs, S, 2)
+    counts = np.empty((2 * n_pairs, S), np.int32)
+    counts[0::2] = ab[:, :, 0]
+    counts[1::2] = ab[:, :, 1]
+    n = 2 * n_pairs
+    row_ptr = np.arange(n + 1, dtype=np.int64)
+    col = (np.arange(n, dtype=np.int32) ^ 1)               # rows 2i and 2i + 1 are each other's only neighbour
+    psi = O.calculate_psi_vectorised(counts, row_ptr, col)[0]
+    want = O.quantize3_fast(psi)
+    x1000 = psi[np.isfinite(psi)].astype(np.float64) * 1000.0
+    assert (np.abs(x1000 - np.floor(x1000) - 0.5) == 0).sum() > 50            # exact ties are in the fixture
+    two_pass = ctx.quantize3(ctx.ps(counts, row_ptr, col))
+    ctx.set_param("ps.quantize3", 1)
+    try:
+        fused = ctx.ps(counts, row_ptr, col)
+    finally:
+        ctx.set_param("ps.quantize3", 0)
+    assert np.array_equal(two_pass, want, equal_nan=True)
+    assert np.array_equal(fused, want, equal_nan=True)
+
+
 def test_ps_empty(ctx):
     ps = ctx.ps(np.zeros((0, 5), np.int32), np.zeros(1, np.int64), np.zeros(0, np.int32))
     assert ps.shape == (0, 5)
