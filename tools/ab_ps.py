@@ -10,7 +10,7 @@ from splicedice_amd.engine import Context
 n, s = int(sys.argv[1]), int(sys.argv[2])
 cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[3:]]
 keys = sorted({k for c in cfgs for k in c})
-DEFAULTS = {"halo_rows": -1, "tile_rows": 0, "chunk_cols": 0, "dma": 0, "use_reach": 1, "nt_loads": 1, "prio": 1, "xcd_remap": 1, "dma_ablate": 0}
+DEFAULTS = {"halo_rows": -1, "tile_rows": 0, "chunk_cols": 0, "dma": 0, "use_reach": 1, "nt_loads": 1, "prio": 1, "xcd_remap": 1, "dma_ablate": 0, "quantize3": 0}
 ctx = Context(0)
 cr, l, r, st = synth.make_junctions(n, 2)
 d = [ctx.to_device(x) for x in (cr, l, r, st)]
