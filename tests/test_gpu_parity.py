@@ -600,6 +600,27 @@ def test_fisher_pairs_walks_across_the_mode_with_tiny_p(ctx):
     np.testing.assert_allclose(got, want, rtol=P_RTOL_TIGHT, atol=0)
 
 
+def test_fisher_step_counts(ctx):
+    """fisher.count_steps: the pair kernel's own count of issued and useful lane-steps (bench.py's useful_lane_frac) -- the
+    useful ones can be no more than the support sizes allow and no fewer than one trip's worth per walked side; results
+    are the same numbers with the counting build"""
+    incl = synth.make_counts(50, 24, 5, mean=40)
+    excl = synth.make_counts(50, 24, 6, mean=160).astype(np.int64)
+    plain = ctx.fisher_pairs(incl, excl)
+    ctx.set_param("fisher.count_steps", 1)
+    try:
+        counted = ctx.fisher_pairs(incl, excl)
+        useful, issued = ctx.fisher_step_stats()
+    finally:
+        ctx.set_param("fisher.count_steps", 0)
+    assert np.array_equal(plain, counted)
+    a = incl[:, :, None].astype(np.int64); b = incl[:, None, :].astype(np.int64)
+    c = excl[:, :, None]; d = excl[:, None, :]
+    iu = np.triu_indices(24, 1)
+    support = (np.minimum(a, d) + np.minimum(b, c))[:, iu[0], iu[1]].sum()         # steps if no tail were cut
+    assert 0 < useful <= support and useful <= issued and issued % 64 == 0
+
+
 def test_fisher_pairs_long_walks_and_sparse_rows(ctx):
     """the pair kernel's state machine on walks of hundreds of steps (counts in the thousands: the products P, Q, S are
     rescaled every few steps, the negligible-tail cut ends the walks) and on sparse rows (most pairs have a zero margin
