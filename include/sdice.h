@@ -46,6 +46,10 @@ const char* sdice_last_error(void);
 int         sdice_ctx_create(int device_ordinal, sdice_ctx** out);
 int         sdice_ctx_destroy(sdice_ctx* ctx);
 int         sdice_sync(sdice_ctx* ctx);
+/* synchronise and hand the context's cached device scratch (the per-call arena, kept between calls) back to the
+ * driver; a long-lived context calls it after an unusually large job (no reference counterpart: the reference's
+ * numpy temporaries die with each call, e.g. pairwise_fisher.py:187-191) */
+int         sdice_trim(sdice_ctx* ctx);
 /* name: caller buffer of name_cap bytes; any out pointer may be NULL */
 int         sdice_device_info(sdice_ctx* ctx, char* name, int name_cap, int* compute_units,
                               int64_t* hbm_bytes);

@@ -26,6 +26,7 @@ SIGNATURES = {
     "sdice_ctx_create": [C.c_int, C.POINTER(ctxp)],
     "sdice_ctx_destroy": [ctxp],
     "sdice_sync": [ctxp],
+    "sdice_trim": [ctxp],
     "sdice_device_info": [ctxp, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p],
     "sdice_dmalloc": [ctxp, C.c_int64, C.POINTER(vp)],
     "sdice_dfree": [ctxp, vp],

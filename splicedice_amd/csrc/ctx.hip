@@ -146,6 +146,14 @@ extern "C" int sdice_sync(sdice_ctx* ctx) {
     return sd_cluster_resolve(ctx);      // (reports the deferred status of an asynchronous clustering)
 }
 
+extern "C" int sdice_trim(sdice_ctx* ctx) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->arena.release();
+    return sd_cluster_resolve(ctx);
+}
+
 extern "C" int sdice_device_info(sdice_ctx* ctx, char* name, int name_cap, int* compute_units,
                                  int64_t* hbm_bytes) {
     SD_ARG(ctx, "ctx is NULL");
@@ -216,7 +224,7 @@ static hipEvent_t pool_get(sdice_ctx* ctx) {
 int sd_prof_begin(sdice_ctx* ctx, const char* name) {
     if (!ctx->prof_on) return -1;
     if (ctx->prof_mode == 2) {          // only the dominant kernel of each path
-        static const char* const kDominant[] = {"ps_tile_v3_kernel", "ps_tile_dma_kernel", "ps_tile_kernel", "ranksum_wave_kernel",
+        static const char* const kDominant[] = {"ps_tile_v3_kernel", "ps_tile_kernel", "ranksum_wave_kernel",
                                                 "ranksum_count_kernel", "ranksum_pair_kernel", "ranksum_pairq_kernel",
                                                 "ranksum_lane_kernel", "ranksum_block_kernel", "fisher_pairs_kernel", "rccl_allgather"};
         bool hit = false;
@@ -326,7 +334,7 @@ extern "C" int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms) {
 extern "C" int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value) {
     SD_ARG(ctx && name, "bad arguments");
     static const char* known[] = {"ps.lds_bytes", "ps.tile_rows", "ps.threads", "ps.chunk_cols",
-                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "cluster.max_nnz", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "ps.dma", "ps.use_reach", "ps.dma_ablate", "sort.rounds", "ranksum.variant", "ranksum.ablate",
+                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "cluster.max_nnz", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "ps.gen1", "ps.use_reach", "sort.rounds", "ranksum.variant", "ranksum.ablate",
                                   "fisher.table_max", "fisher.refill", "fisher.unroll", "fisher.count_steps", "bh.columns_path", "bh.vector_path", "bhv.mean", "bhv.cap", "bh.reg_cap", "bh.mean", "bh.spb", nullptr};
     for (int i = 0; known[i]; ++i)
         if (strcmp(known[i], name) == 0) {

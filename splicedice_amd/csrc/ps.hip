@@ -31,6 +31,7 @@
 // if the exact quotient were within 2^-53 of a float32 midpoint, impossible for a
 // denominator below 2^24).  Otherwise 64-bit sums and the float64 division are used.
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -52,10 +53,9 @@ struct PsArgs {
     int n_chunks;       // column chunks per row tile
     int prio;           // raise the wave priority while the window loads go out (param ps.prio, default 1)
     int nt;             // non-temporal window loads (param ps.nt_loads, default 1; unchunked tables only)
-    // LDS-DMA kernel only:
+    // second-generation kernel only:
     const uint32_t* reach;  // reach words of the lists per block of 16 rows (below | beyond << 8, 255 = that far or further), NULL: stage `halo` rows
-    int lv_shift;       // column chunks: log2(row segments of a chunk per 1 KiB piece) (chunk_cols / 4 divides 64)
-    int dbg;            // timing experiments on the LDS-DMA kernel (param ps.dma_ablate; results are wrong when set)
+    int lv_shift;       // column chunks: 6 - log2(vectors per row segment) (chunk_cols / 4 divides 64)
 };
 
 __device__ __forceinline__ int4 nt_load(const int4* p) {
@@ -428,61 +428,6 @@ __global__ void __launch_bounds__(1024) ps_tile_kernel(PsArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the tile kernel (VEC = 4 tables; the default).  Same tile / item scheme, but
-//   * the window goes global -> LDS by `global_load_lds_dwordx4` (1 KiB per wave instruction, no VGPRs, no
-//     ds_write pass, nothing for the VALU to do): a wave sends out its share of the tile's OWN rows first;
-//   * the halo is sized per tile from the reach that the clustering kernel leaves next to its lists, one word per
-//     block of 16 rows (neighbours_kernel, cluster_fast.hip; tiles are whole blocks): 16 rows in all on gene-shaped
-//     data instead of 2 x 16 fixed, and no neighbour misses the window (a list reaching further than the LDS holds,
-//     or a foreign CSR without reach words and a far neighbour, still takes the global-memory item path: any valid
-//     CSR is exact);
-//   * the tile's uniform scalars (first / last row pointer, four reach words) are SCALAR loads in one asm
-//     statement: they return on lgkmcnt, so waiting for them does not drain the DMA queue (hipcc waits vmcnt(0)
-//     for any vector load of its own while a DMA is in flight; asm vector loads with counted waits were tried --
-//     hipcc copies their destination registers ahead of the wait statement, i.e. before the data has landed);
-//   * the per-tile count bound is taken from LDS after the window has landed; flags go through per-wave LDS
-//     slots (no initialisation, no atomics).
-// LDS-DMA honours EXEC (tools/mb/dma_exec.hip: inactive lanes neither load nor store, active lanes keep their
-// lane slot), and its instruction offset moves the global AND the LDS address (tools/mb/psring.hip).
-// One all-zero row sits behind the window (short neighbour batches are padded with it).
-template <bool NT> __device__ __forceinline__ void glds16(const void* gbase, unsigned voff, unsigned lds_dst) {
-    // lane l: 16 B from gbase + voff (gbase and lds_dst wave-uniform, voff per lane) to LDS lds_dst + 16 l; M0 saved and restored
-    unsigned keep;
-    if (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds4(const void* gbase, unsigned voff, unsigned lds_dst) {
-    // lane l: 4 B from gbase + voff to LDS lds_dst + 4 l
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
-}
-// `bytes` contiguous bytes from gbase -> LDS from lds0, 1 KiB pieces; piece q goes to the wave with wave_rel == q mod NW
-template <bool NT>
-__device__ __forceinline__ void dma_run(const char* gbase, int bytes, unsigned lds0, int wave_rel, int NW, unsigned lane16) {
-    for (int off = wave_rel << 10; off < bytes; off += NW << 10)
-        if ((int)(off + lane16) < bytes) glds16<NT>(gbase, (unsigned)off + lane16, lds0 + (unsigned)off);
-}
-// `rows` row segments of one column chunk (LDS rows of 64 >> rsh vectors, V of them valid; 1 << rsh segments per piece)
-template <bool NT>
-__device__ __forceinline__ void dma_chunk_rows(const char* gbase, int rows, unsigned lds0, int wave_rel, int NW, int lane, int rsh,
-                                               int V, unsigned row_stride_bytes) {
-    const int lv = 64 >> rsh;
-    const int lr = lane >> (6 - rsh), cc = lane & (lv - 1);
-    const int npieces = (rows + (1 << rsh) - 1) >> rsh;
-    unsigned voff = ((unsigned)(wave_rel << rsh) + (unsigned)lr) * row_stride_bytes + (unsigned)cc * 16u;
-    const unsigned vstep = ((unsigned)NW << rsh) * row_stride_bytes;
-    for (int p = wave_rel; p < npieces; p += NW) {
-        if (cc < V && (p << rsh) + lr < rows) glds16<NT>(gbase, voff, lds0 + ((unsigned)p << 10));
-        voff += vstep;
-    }
-}
-
 // maximum over the 64 lanes by DPP steps (VALU latency; six ds_bpermute round trips on the tile's critical path were
 // measurable): the result is valid in lane 63
 __device__ __forceinline__ unsigned wave_max_dpp(unsigned x) {
@@ -494,238 +439,11 @@ __device__ __forceinline__ unsigned wave_max_dpp(unsigned x) {
     x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true));   // row_bcast:31 -> rows 2, 3
     return x;
 }
-// largest count in the pieces that dma_run / dma_chunk_rows with the same arguments fetched for THIS wave (after its own
-// s_waitcnt vmcnt(0) they are visible to it: no barrier needed)
-__device__ __forceinline__ unsigned max_run(const char* ldsB, int bytes, int lds0, int wave_rel, int NW, unsigned lane16, unsigned m) {
-    // four reads in flight per trip (one LDS round trip instead of four on the tile's critical path)
-    const int step = NW << 10;
-    for (int off = (wave_rel << 10) + (int)lane16; off < bytes; off += 4 * step) {
-        const bool b1 = off + step < bytes, b2 = off + 2 * step < bytes, b3 = off + 3 * step < bytes;
-        const int4 z = make_int4(0, 0, 0, 0);
-        const int4 v0 = *reinterpret_cast<const int4*>(ldsB + lds0 + off);
-        const int4 v1 = b1 ? *reinterpret_cast<const int4*>(ldsB + lds0 + off + step) : z;
-        const int4 v2 = b2 ? *reinterpret_cast<const int4*>(ldsB + lds0 + off + 2 * step) : z;
-        const int4 v3 = b3 ? *reinterpret_cast<const int4*>(ldsB + lds0 + off + 3 * step) : z;
-        m = max(max(m, vmax(v0)), max(vmax(v1), max(vmax(v2), vmax(v3))));
-    }
-    return m;
-}
-__device__ __forceinline__ unsigned max_chunk_rows(const char* ldsB, int rows, int lds0, int wave_rel, int NW, int lane, int rsh, int V, unsigned m) {
-    const int lv = 64 >> rsh;
-    const int lr = lane >> (6 - rsh), cc = lane & (lv - 1);
-    if (cc >= V) return m;
-    const int lim = rows - lr;                              // piece p holds a row of this lane iff (p << rsh) < lim
-    const char* base = ldsB + lds0 + lane * 16;
-    for (int p = wave_rel; (p << rsh) < lim; p += 4 * NW) {
-        const bool b1 = ((p + NW) << rsh) < lim, b2 = ((p + 2 * NW) << rsh) < lim, b3 = ((p + 3 * NW) << rsh) < lim;
-        const int4 z = make_int4(0, 0, 0, 0);
-        const int4 v0 = *reinterpret_cast<const int4*>(base + (p << 10));
-        const int4 v1 = b1 ? *reinterpret_cast<const int4*>(base + ((p + NW) << 10)) : z;
-        const int4 v2 = b2 ? *reinterpret_cast<const int4*>(base + ((p + 2 * NW) << 10)) : z;
-        const int4 v3 = b3 ? *reinterpret_cast<const int4*>(base + ((p + 3 * NW) << 10)) : z;
-        m = max(max(m, vmax(v0)), max(vmax(v1), max(vmax(v2), vmax(v3))));
-    }
-    return m;
-}
-
-template <bool CHUNKED, bool WEXCL, bool WPS, bool Q3>
-__global__ void __launch_bounds__(1024, 8) ps_tile_dma_kernel(PsArgs a) {      // 64 VGPRs: 32 waves per CU
-    extern __shared__ int4 smem4[];
-    constexpr int VEC = 4;
-    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = T >> 6;
-    const int win_cap = a.tile_rows + 2 * a.halo;
-    int* tileL = reinterpret_cast<int*>(smem4);
-    int* colL = tileL + (win_cap + 1) * a.chunk_cols;            // row win_cap is the all-zero padding row
-    int* rpS = colL + a.col_cap;                                 // the tile's row pointers as they stand in HBM (int64; the low words are used)
-    unsigned* red = reinterpret_cast<unsigned*>(rpS + ((2 * (a.tile_rows + 1) + 3) & ~3));   // one word per wave (16-byte aligned), see below
-
-    const int bid = blockIdx.x;
-    int tile, chunk = 0;
-    if (!CHUNKED) {
-        tile = a.tiles_per_xcd ? (bid & 7) * a.tiles_per_xcd + (bid >> 3) : bid;
-    } else {
-        tile = bid / a.n_chunks;
-        chunk = bid - tile * a.n_chunks;
-        if (a.tiles_per_xcd) {
-            const int k = bid >> 3;
-            const int t_local = k / a.n_chunks;
-            chunk = k - t_local * a.n_chunks;
-            tile = (bid & 7) * a.tiles_per_xcd + t_local;
-        }
-    }
-    if (tile >= a.n_tiles) return;
-    const int c0 = chunk * a.chunk_cols;
-    const int cwc = CHUNKED ? min(a.chunk_cols, a.s - c0) : a.s;
-    const int V = cwc / VEC;
-    const int ldw = a.chunk_cols, LV = ldw / VEC;
-    const int r0 = tile * a.tile_rows;                     // (n < 2^31)
-    const int nr = min(a.tile_rows, (int)a.n - r0);
-    const int wbase = r0 - a.halo;                         // row that LDS window row 0 stands for (may be negative)
-    const unsigned lds_win = (unsigned)(uintptr_t)tileL;
-    const int rowb = ldw * 4;
-    const unsigned lane16 = (unsigned)lane * 16u;
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    for (int i = tid; i < LV; i += T) reinterpret_cast<int4*>(tileL + win_cap * a.chunk_cols)[i] = make_int4(0, 0, 0, 0);
-    const int zero_off = win_cap * a.chunk_cols * 4;
-
-    // ---- the tile's own rows go out first (they depend on nothing but the tile index)
-    const char* gtile = reinterpret_cast<const char*>(a.counts + (int64_t)r0 * a.s + c0);
-    const unsigned row_stride = (unsigned)a.s * 4u;
-    if (!CHUNKED) {
-        if (a.nt) dma_run<true>(gtile, nr * rowb, lds_win + (unsigned)(a.halo * rowb), wave, NW, lane16);
-        else      dma_run<false>(gtile, nr * rowb, lds_win + (unsigned)(a.halo * rowb), wave, NW, lane16);
-    } else {
-        dma_chunk_rows<false>(gtile, nr, lds_win + (unsigned)(a.halo * rowb), wave, NW, lane, a.lv_shift, V, row_stride);
-    }
-
-    // ---- uniform scalars of the tile: first / last row pointer, reach words of its two first and two last blocks
-    long long kbase, kend;
-    int nlo = a.halo, nhi = a.halo;
-    {
-        const int64_t* pf = a.row_ptr + r0;
-        const int64_t* pl = pf + nr;
-        if (a.dbg & 4) { kbase = 0; kend = 0; nlo = nhi = a.halo >> 1; }
-        else if (a.reach) {
-            const int b0 = r0 >> 4, bl = (r0 + nr - 1) >> 4;
-            const uint32_t* q0 = a.reach + b0;
-            const uint32_t* q1 = a.reach + min(b0 + 1, bl);
-            const uint32_t* q2 = a.reach + max(bl - 1, b0);
-            const uint32_t* q3 = a.reach + bl;
-            unsigned w0, w1, w2, w3;
-            asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %6, 0x0\n\ts_load_dwordx2 %1, %7, 0x0\n\t"
-                         "s_load_dword %2, %8, 0x0\n\ts_load_dword %3, %9, 0x0\n\t"
-                         "s_load_dword %4, %10, 0x0\n\ts_load_dword %5, %11, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(kbase), "=&s"(kend), "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
-                         : "s"(pf), "s"(pl), "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory");
-            // block b reaches (w & 255) rows below row 16 b and (w >> 8 & 255) rows beyond row 16 b + 15
-            const int e = r0 + nr - 1;
-            int lo_need = (int)(w0 & 255u);
-            if (b0 < bl) lo_need = max(lo_need, (int)(w1 & 255u) - 16);
-            int hi_need = ((bl << 4) + 15 + (int)((w3 >> 8) & 255u)) - e;
-            if (b0 < bl) hi_need = max(hi_need, (bl << 4) - 1 + (int)((w2 >> 8) & 255u) - e);
-            nlo = min(max(lo_need, 0), a.halo);
-            nhi = min(max(hi_need, 0), a.halo);
-        } else {
-            asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(kbase), "=&s"(kend) : "s"(pf), "s"(pl) : "memory");
-        }
-    }
-    const int nk = (int)(kend - kbase);
-
-    // ---- halo rows (what the lists of this tile reach beyond it, capped by the LDS window) and the row pointers
-    const int slo = max(0, r0 - nlo);
-    const int shi = min((int)a.n, r0 + nr + nhi);
-    const int wrows = shi - slo;
-    {
-        const int lo_rows = r0 - slo, hi_rows = shi - (r0 + nr);
-        int w_lo = wave - (NW >> 1);      if (w_lo < 0) w_lo += NW;       // (not the waves that took the first window pieces)
-        int w_hi = wave - (NW >> 1) - 1;  if (w_hi < 0) w_hi += NW;
-        const char* glo = gtile - (int64_t)lo_rows * row_stride;
-        const char* ghi = gtile + (int64_t)nr * row_stride;
-        if (!CHUNKED) {
-            if (a.nt) {
-                dma_run<true>(glo, lo_rows * rowb, lds_win + (unsigned)((slo - wbase) * rowb), w_lo, NW, lane16);
-                dma_run<true>(ghi, hi_rows * rowb, lds_win + (unsigned)((a.halo + nr) * rowb), w_hi, NW, lane16);
-            } else {
-                dma_run<false>(glo, lo_rows * rowb, lds_win + (unsigned)((slo - wbase) * rowb), w_lo, NW, lane16);
-                dma_run<false>(ghi, hi_rows * rowb, lds_win + (unsigned)((a.halo + nr) * rowb), w_hi, NW, lane16);
-            }
-        } else {
-            dma_chunk_rows<false>(glo, lo_rows, lds_win + (unsigned)((slo - wbase) * rowb), w_lo, NW, lane, a.lv_shift, V, row_stride);
-            dma_chunk_rows<false>(ghi, hi_rows, lds_win + (unsigned)((a.halo + nr) * rowb), w_hi, NW, lane, a.lv_shift, V, row_stride);
-        }
-        // the tile's nr + 1 row pointers, raw, 64 dwords per instruction
-        int w_rp = wave - 3;  while (w_rp < 0) w_rp += NW;
-        const int nd = 2 * (nr + 1);
-        for (int q = w_rp; q * 64 < nd; q += NW)
-            if (q * 64 + lane < nd) glds4(a.row_ptr + r0, (unsigned)(q * 64 + lane) * 4u, (unsigned)(uintptr_t)rpS + (unsigned)q * 256u);
-    }
-    if (a.prio) __builtin_amdgcn_s_setprio(0);
-
-    // ---- neighbour indices -> LDS byte offsets of their rows (or -1 - index for a row outside the window)
-    const bool col_in_lds = nk <= a.col_cap;
-    bool outside = false;
-    if (col_in_lds && !(a.dbg & 2)) {
-        for (int k = tid; k < nk; k += T) {
-            const int j = a.col[kbase + k];
-            const bool in = (unsigned)(j - slo) < (unsigned)wrows;
-            outside = outside || !in;
-            colL[k] = in ? (j - wbase) * rowb : -1 - j;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
-    // ---- bound of the tile: the largest staged count, every wave over the pieces it fetched itself (no second barrier,
-    // no second pass: a pass of all threads over the window between two barriers cost 13 % of the kernel)
-    {
-        unsigned cmax = 0;
-        if (!(a.dbg & 1)) {
-            const char* ldsB = reinterpret_cast<const char*>(tileL);
-            const int lo_rows = r0 - slo, hi_rows = shi - (r0 + nr);
-            int w_lo = wave - (NW >> 1);      if (w_lo < 0) w_lo += NW;
-            int w_hi = wave - (NW >> 1) - 1;  if (w_hi < 0) w_hi += NW;
-            if (!CHUNKED) {
-                cmax = max_run(ldsB, nr * rowb, a.halo * rowb, wave, NW, lane16, cmax);
-                cmax = max_run(ldsB, lo_rows * rowb, (slo - wbase) * rowb, w_lo, NW, lane16, cmax);
-                cmax = max_run(ldsB, hi_rows * rowb, (a.halo + nr) * rowb, w_hi, NW, lane16, cmax);
-            } else {
-                cmax = max_chunk_rows(ldsB, nr, a.halo * rowb, wave, NW, lane, a.lv_shift, V, cmax);
-                cmax = max_chunk_rows(ldsB, lo_rows, (slo - wbase) * rowb, w_lo, NW, lane, a.lv_shift, V, cmax);
-                cmax = max_chunk_rows(ldsB, hi_rows, (a.halo + nr) * rowb, w_hi, NW, lane, a.lv_shift, V, cmax);
-            }
-            cmax = wave_max_dpp(cmax);
-        }
-        const unsigned long long any_out = __ballot(outside);
-        // one word per wave: the largest count it fetched (saturating at 2^24: beyond that no item is fast), bit 31 = one of
-        // its staged neighbours is outside the window; sixteen words are read back, wave 0 clears the unused ones
-        if (lane == 63) red[wave] = min(cmax, 0x1000000u) | (any_out != 0ull ? 0x80000000u : 0u);
-        if (wave == 0 && lane >= NW && lane < 16) red[lane] = 0u;
-    }
-    __syncthreads();
-    unsigned tile_cmax = 0u, tile_or = 0u;
-    if (!(a.dbg & 16)) {
-        // every thread reads all sixteen words (four broadcast reads in flight: ONE LDS round trip)
-        const uint4* r4 = reinterpret_cast<const uint4*>(red);
-        const uint4 x0 = r4[0], x1 = r4[1], x2 = r4[2], x3 = r4[3];
-        tile_or = (x0.x | x0.y | x0.z | x0.w) | (x1.x | x1.y | x1.z | x1.w) | (x2.x | x2.y | x2.z | x2.w) | (x3.x | x3.y | x3.z | x3.w);
-        const unsigned k = 0x7fffffffu;
-        const unsigned m0 = max(max(x0.x & k, x0.y & k), max(x0.z & k, x0.w & k)), m1 = max(max(x1.x & k, x1.y & k), max(x1.z & k, x1.w & k));
-        const unsigned m2 = max(max(x2.x & k, x2.y & k), max(x2.z & k, x2.w & k)), m3 = max(max(x3.x & k, x3.y & k), max(x3.z & k, x3.w & k));
-        tile_cmax = max(max(m0, m1), max(m2, m3));
-    }
-    tile_cmax = (unsigned)__builtin_amdgcn_readfirstlane((int)tile_cmax);
-    // an item is fast (32-bit sums, float32 quotient) iff (degree + 1) * (largest count of the tile) < 2^24
-    const bool fast_tile = tile_cmax <= 0xFFFFFFu && col_in_lds;                         // block-uniform
-    const bool all_in = __builtin_amdgcn_readfirstlane((int)tile_or) >= 0;               // block-uniform: no per-batch window check needed
-
-    // ---- per (row, vector) item: gather neighbours from LDS, divide, store
-    {
-        const char* tileB = reinterpret_cast<const char*>(tileL);
-        const int items = nr * V;
-        int ri = tid / V, c = tid - ri * V;
-        const int dr = T / V, dc = T - dr * V;
-        const int kb = (int)kbase;
-        for (int it = tid; it < items; it += T) {
-            const int k0 = rpS[2 * ri] - kb, k1 = (a.dbg & 2) ? k0 : rpS[2 * ri + 2] - kb;   // (differences of the low words: lists are < 2^31 entries)
-            const int64_t o = (int64_t)(r0 + ri) * a.s + c0 + c * VEC;
-            const int own_off = (a.halo + ri) * rowb;
-            bool done = false;
-            const unsigned deg = (unsigned)(k1 - k0);
-            if (fast_tile && ((a.dbg & 8) || (deg < 254u && __umul24(deg + 1u, tile_cmax) <= 0xFFFFFFu)))
-                done = all_in ? ps_item_fast<VEC, WEXCL, WPS, false, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off)
-                              : ps_item_fast<VEC, WEXCL, WPS, true, Q3, 0>(a, tileB, colL, k0, k1, c * VEC * 4, own_off, o, zero_off);
-            if (!done)
-                ps_item_slow<VEC, WEXCL, WPS, Q3, 0>(a, tileB, colL, col_in_lds, kbase, k0, k1, slo, wrows, ldw, c0, c * VEC,
-                                                     own_off, o, wbase);
-            c += dc; ri += dr;
-            if (c >= V) { c -= V; ri += 1; }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
-// Register-staged tile kernel, second generation (VEC = 4 tables).  What the LDS-DMA experiments taught, applied to
-// the register path (which gets the tile's count bound for free while the vectors pass through the VGPRs):
+// Register-staged tile kernel, second generation (VEC = 4 tables).  The window passes through the VGPRs
+// (which gives the tile's count bound for free; an LDS-DMA staging, global_load_lds_dwordx4, was built in round 3,
+// bit-exact and slower -- DESIGN appendix A.3):
 //   * EVERY global load of the tile is issued before the first one is waited for: the tile's own rows (up to four
 //     vectors per thread), then -- behind one scalar-load round trip for the first / last row pointer and the reach
 //     words -- the halo rows the lists really reach (reach words of the clustering kernel, 16 rows in all on
@@ -864,8 +582,13 @@ __global__ void __launch_bounds__(1024, 8) ps_tile_v3_kernel(PsArgs a) {
     // ---- (4) neighbour indices (three per thread) and (5) row pointers (two per thread)
     const bool col_in_lds = nk <= a.col_cap && nk <= 3 * T;
     int jv[3];
+    {
+        // (clamped; a tile without list entries reads the row pointers instead: a.col may end exactly at kbase, or be NULL)
+        const int* cbase = nk > 0 ? a.col + kbase : reinterpret_cast<const int*>(a.row_ptr + r0);
+        const int last = col_in_lds ? max(nk - 1, 0) : 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int kk = tid + k * T; jv[k] = a.col[kbase + (col_in_lds ? min(kk, max(nk - 1, 0)) : 0)]; }
+        for (int k = 0; k < 3; ++k) jv[k] = cbase[min(tid + k * T, last)];
+    }
     int rp_mine[2];                                         // (low words: a tile's lists are < 2^31 entries)
     rp_mine[0] = reinterpret_cast<const int*>(a.row_ptr + r0 + min(tid, nr))[0];
     rp_mine[1] = reinterpret_cast<const int*>(a.row_ptr + r0 + min(tid + T, nr))[0];
@@ -991,22 +714,6 @@ int launch_ps_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3
 }
 
 template <bool CH, bool WE, bool WP, bool Q3>
-int launch_ps_dma_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_dma_kernel<CH, WE, WP, Q3>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_LAUNCH(ctx, "ps_tile_dma_kernel", (ps_tile_dma_kernel<CH, WE, WP, Q3>), grid, dim3(threads), lds, a);
-    return SDICE_OK;
-}
-template <bool CH>
-int launch_ps_dma(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid, bool wexcl, bool wps, bool q3) {
-    if (wexcl && wps) return q3 ? launch_ps_dma_one<CH, true, true, true>(ctx, a, threads, lds, grid)
-                                : launch_ps_dma_one<CH, true, true, false>(ctx, a, threads, lds, grid);
-    if (wexcl) return launch_ps_dma_one<CH, true, false, false>(ctx, a, threads, lds, grid);
-    return q3 ? launch_ps_dma_one<CH, false, true, true>(ctx, a, threads, lds, grid)
-              : launch_ps_dma_one<CH, false, true, false>(ctx, a, threads, lds, grid);
-}
-
-template <bool CH, bool WE, bool WP, bool Q3>
 int launch_ps_v3_one(sdice_ctx* ctx, const PsArgs& a, int threads, size_t lds, dim3 grid) {
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ps_tile_v3_kernel<CH, WE, WP, Q3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1066,15 +773,13 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     if (cw > s) cw = s;
     if (vec == 4) cw = (cw / 4) * 4;
     if (cw < vec) cw = vec;
-    // kernel: 0 = second-generation register-staged kernel (ps_tile_v3_kernel, the default), 1 = LDS-DMA kernel
-    // (ps_tile_dma_kernel), 2 = first-generation kernel (ps_tile_kernel; also serves tables whose rows are not 16-byte
-    // vectors, column chunks whose vectors do not divide 64, and the timing experiments)
+    // kernel: 0 = second-generation register-staged kernel (ps_tile_v3_kernel, the default), 2 = first-generation kernel
+    // (ps_tile_kernel; also serves tables whose rows are not 16-byte vectors, column chunks whose vectors do not divide
+    // 64, tile shapes beyond the register staging of the newer kernel, and the timing experiments)
     const bool pow2chunk = cw == s || (cw / 4 <= 64 && 64 % (cw / 4) == 0);
-    int kern = (int)ctx->param("ps.dma", 0);
-    if (vec != 4 || abl != 0 || !pow2chunk || kern < 0 || kern > 2) kern = 2;
-    if ((int64_t)s * 2048 >= ((int64_t)1 << 30)) kern = 2;       // (the newer kernels address a tile's outputs by 32-bit offsets)
-    const bool dma = kern == 1;
-    const bool newk = kern != 2;
+    int kern = ctx->param("ps.gen1", 0) != 0 ? 2 : 0;
+    if (vec != 4 || abl != 0 || !pow2chunk) kern = 2;
+    if ((int64_t)s * 2048 >= ((int64_t)1 << 30)) kern = 2;       // (the newer kernel addresses a tile's outputs by 32-bit offsets)
     int64_t lds = ctx->param("ps.lds_bytes", 80 * 1024);   // two workgroups per CU (160 KiB LDS)
     if (lds > 160 * 1024) lds = 160 * 1024;
     if (lds < 8 * 1024) lds = 8 * 1024;
@@ -1082,53 +787,67 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     threads = (threads / 64) * 64;
     if (threads < 64) threads = 64;
     if (threads > 1024) threads = 1024;
+    const int64_t LV = vec == 4 ? cw / 4 : cw;              // 16-byte vectors of a window row
 
-    // LDS budget (ints): (R + 2H) * cw window + 16 R staged neighbour offsets + (R + 1) row
-    // pointers + 8 scratch
-    const int64_t L = lds / 4 - (newk ? 64 : 16);      // (the newer kernels keep 16 per-wave words behind the row pointers)
-    const bool have_reach = newk && d_col != nullptr && d_col == ctx->d_col && ctx->reach_n == n && ctx->d_reach != nullptr &&
-                            ctx->param("ps.use_reach", 1) != 0;
-    int64_t H = ctx->param("ps.halo_rows", -1);
-    if (H < 0) {
-        // rows further than the halo are still summed exactly (global-memory path).  With reach bytes H is the
-        // CAPACITY of the window on each side (a tile stages what its lists reach, 8 + 8 rows on average on
-        // gene-shaped data, 22 at most); without them H rows are staged on each side: 16 cover >99.9 % of the
-        // neighbours of gene-shaped data, less if the clustering saw a smaller reach
-        H = 16;
-        if (!have_reach && d_col != nullptr && d_col == ctx->d_col && ctx->cluster_reach > 0 && ctx->cluster_reach < H)
-            H = ctx->cluster_reach;
+    int64_t R = 0, H = 0;
+    bool have_reach = false;
+    // tile geometry; a shape that the register staging of the second-generation kernel cannot hold (it stages FOUR
+    // vectors of the tile's own rows, TWO of each halo run and the low words of TWO row pointers per thread) falls back
+    // to the first-generation kernel, whose loops take any shape
+    for (;;) {
+        const bool newk = kern == 0;
+        // LDS budget (ints): (R + 2H + 1) * cw window + 16 R staged neighbour offsets + (R + 1) row pointers + scratch
+        const int64_t L = lds / 4 - (newk ? 64 : 16);      // (the newer kernel keeps 16 per-wave words behind the row pointers)
+        have_reach = newk && d_col != nullptr && d_col == ctx->d_col && ctx->reach_n == n && ctx->d_reach != nullptr &&
+                     ctx->param("ps.use_reach", 1) != 0;
+        H = ctx->param("ps.halo_rows", -1);
+        const bool h_auto = H < 0;
+        if (h_auto) {
+            // rows further than the halo are still summed exactly (global-memory path).  With reach bytes H is the
+            // CAPACITY of the window on each side (a tile stages what its lists reach, 8 + 8 rows on average on
+            // gene-shaped data, 22 at most); without them H rows are staged on each side: 16 cover >99.9 % of the
+            // neighbours of gene-shaped data, less if the clustering saw a smaller reach
+            H = 16;
+            if (!have_reach && d_col != nullptr && d_col == ctx->d_col && ctx->cluster_reach > 0 && ctx->cluster_reach < H)
+                H = ctx->cluster_reach;
+        }
+        // (a software-pipelined persistent variant -- one workgroup per CU, two LDS buffers, next tile's
+        //  loads in flight during the gather -- was built and measured 30 % slower: the kernel is VALU-issue
+        //  bound, and halving the resident waves costs more than hiding the load latency gains)
+        // caps of the register staging: rows <= 4 T / LV (own rows), rows <= 2 T - 1 (row pointers: nr + 1 of them),
+        // halo <= T / LV (the two runs together take two vectors per thread)
+        const int64_t r_cap = newk ? std::min<int64_t>(4 * (int64_t)threads / LV, 2 * (int64_t)threads - 1) : 2 * (int64_t)threads;
+        const int64_t h_cap = newk ? (int64_t)threads / LV : (int64_t)1 << 20;
+        if (H > h_cap) H = h_cap;
+        const int64_t per_row = 17;      // 16 staged neighbour offsets + the row pointer
+        const int64_t r_param = ctx->param("ps.tile_rows", 0);
+        auto fit_rows = [&](int64_t h) {
+            int64_t r = r_param > 0 ? r_param : (L - (2 * h + 1) * cw) / (cw + per_row);
+            return std::min(r, r_cap);
+        };
+        R = fit_rows(H);
+        while (H > 0 && (R < std::min<int64_t>(8, r_cap) || (R + 2 * H + 1) * cw + per_row * R > L)) {
+            // window does not fit: shrink the halo first (misses fall back to global loads), then the tile
+            H = H / 2;
+            R = fit_rows(H);
+        }
+        if (R < 1) R = 1;
+        while (R > 1 && (R + 2 * H + 1) * cw + per_row * R > L) R -= 1;
+        if (newk && (r_cap < 1 || R > r_cap || (R + 2 * H + 1) * cw + per_row * R > L)) { kern = 2; continue; }
+        SD_ARG((R + 2 * H + 1) * cw + per_row * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
+        // (trimming R so that R * V is a multiple of the block size was measured: slower -- the per-tile
+        //  fixed cost outweighs the idle lanes of the last pass over the items)
+        if (have_reach && R >= 16 && r_param <= 0) R &= ~(int64_t)15;   // tiles are whole 16-row reach blocks
+        have_reach = have_reach && R % 16 == 0;
+        if (have_reach && h_auto) {
+            // the rows lost to the rounding are window capacity: a tile stages only what its reach words ask for, so a
+            // larger capacity costs nothing and keeps the rare far-reaching tile off the global-memory path
+            // (2 M x 500: 96-row tiles either way, capacity 16 -> 24, 1.686 -> 1.650 ms)
+            while (H < 32 && H + 1 <= h_cap && (R + 2 * (H + 1) + 1) * cw + per_row * R <= L) H += 1;
+        }
+        break;
     }
-    // (a software-pipelined persistent variant -- one workgroup per CU, two LDS buffers, next tile's
-    //  loads in flight during the gather -- was built and measured 30 % slower: the kernel is VALU-issue
-    //  bound, and halving the resident waves costs more than hiding the load latency gains)
-    if (kern == 0 && H > threads / (cw / 4)) H = threads / (cw / 4);    // (two halo vectors per thread)
-    const int64_t r_max = 2 * threads;   // (the register-staged kernel keeps two row pointers per thread in registers)
-    const int64_t per_row = dma ? 18 : 17;  // 16 staged neighbour offsets + the row pointer (raw int64 in the LDS-DMA kernel)
-    int64_t R = ctx->param("ps.tile_rows", 0);
-    if (R <= 0) R = (L - (2 * H + 1) * cw) / (cw + per_row);
-    if (R > r_max) R = r_max;
-    if (kern == 0 && R > 4 * threads / (cw / 4)) R = 4 * threads / (cw / 4);   // (four vectors of the tile's own rows per thread)
-    if (kern == 0 && R < 1) R = 1;
-    while (H > 0 && (R < 8 || (R + 2 * H + 1) * cw + per_row * R > L)) {
-        // window does not fit: shrink the halo first (misses fall back to global loads), then the tile
-        H = H / 2;
-        if (ctx->param("ps.tile_rows", 0) <= 0) R = (L - (2 * H + 1) * cw) / (cw + per_row);
-        if (R > r_max) R = r_max;
-    }
-    if (R < 1) R = 1;
-    while (R > 1 && (R + 2 * H + 1) * cw + per_row * R > L) R -= 1;
-    SD_ARG((R + 2 * H + 1) * cw + per_row * R <= L, "row chunk does not fit LDS; lower ps.chunk_cols");
-    // (trimming R so that R * V is a multiple of the block size was measured: slower -- the per-tile
-    //  fixed cost outweighs the idle lanes of the last pass over the items)
-    if (have_reach && R >= 16 && ctx->param("ps.tile_rows", 0) <= 0) R &= ~(int64_t)15;   // tiles are whole 16-row reach blocks
-    const bool use_reach = have_reach && R % 16 == 0;
-    if (use_reach && ctx->param("ps.halo_rows", -1) < 0) {
-        // the rows lost to the rounding are window capacity: a tile stages only what its reach words ask for, so a
-        // larger capacity costs nothing and keeps the rare far-reaching tile off the global-memory path
-        // (2 M x 500: 96-row tiles either way, capacity 16 -> 24, 1.686 -> 1.650 ms)
-        const int64_t h_cap = kern == 0 ? threads / (cw / 4) : 32;
-        while (H < 32 && H + 1 <= h_cap && (R + 2 * (H + 1) + 1) * cw + per_row * R <= L) H += 1;
-    }
+    const bool use_reach = have_reach;
     if (R > n) { R = n; }
 
     PsArgs a;
@@ -1146,7 +865,6 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     // the lines shared by two chunks and the halo rows want the L2 (+1.7 % at 2 M x 500): unchunked tables only
     a.nt = ctx->param("ps.nt_loads", 1) != 0 && n_chunks == 1;
     a.reach = use_reach ? ctx->d_reach : nullptr;
-    a.dbg = (int)ctx->param("ps.dma_ablate", 0);
     a.lv_shift = 0;                                        // column chunks: log2(row segments per 1 KiB piece)
     for (int b = 0; b <= 6; ++b) if ((cw / 4) == (64 >> b)) a.lv_shift = b;
     int gx = a.n_tiles;
@@ -1161,8 +879,6 @@ extern "C" int sdice_ps_dev(sdice_ctx* ctx, int64_t n, int32_t s, const int32_t*
     dim3 grid((unsigned)((int64_t)gx * n_chunks));
     if (kern == 0) return n_chunks == 1 && cw == s ? launch_ps_v3<false>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3)
                                                    : launch_ps_v3<true>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3);
-    if (dma) return n_chunks == 1 && cw == s ? launch_ps_dma<false>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3)
-                                             : launch_ps_dma<true>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3);
     if (vec == 4) return launch_ps<4>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
     return launch_ps<1>(ctx, a, threads, lds_bytes, grid, d_excl != nullptr, d_ps != nullptr, q3, abl);
 }

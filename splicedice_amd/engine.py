@@ -102,6 +102,10 @@ class Context:
     def sync(self):
         check(self.lib.sdice_sync(self.h), "sdice_sync")
 
+    def trim(self):
+        """synchronise and release the cached device scratch"""
+        check(self.lib.sdice_trim(self.h), "sdice_trim")
+
     def prof_enable(self, on=True):
         """on: False/0 off, True/1 every kernel, 2 dominant kernels only."""
         check(self.lib.sdice_prof_enable(self.h, int(on)), "sdice_prof_enable")

@@ -275,9 +275,9 @@ def test_ps_vs_oracle(ctx, n, s, seed):
 
 @pytest.mark.parametrize("n,s", [(30000, 100), (20000, 500), (50000, 36), (9000, 1000), (40000, 8)])
 def test_ps_kernel_generations_agree(ctx, n, s):
-    """the three tile kernels behind sdice_ps_dev -- second-generation register-staged (ps.dma = 0, the default),
-    LDS-DMA (1), first generation (2) -- on the device path WITH the clustering's reach words (halo sized per tile),
-    without them (ps.use_reach = 0), with exclusion sums, and with the fused '.3f' store: bit-identical"""
+    """the two tile kernels behind sdice_ps_dev -- second-generation register-staged (the default) and first generation
+    (ps.gen1 = 1: any row width, any tile shape) -- on the device path WITH the clustering's reach words (halo sized per
+    tile), without them (ps.use_reach = 0), with exclusion sums, and with the fused '.3f' store: bit-identical"""
     cr, left, right, strand = synth.make_junctions(n, n + s)
     d = [ctx.to_device(x) for x in (cr, left, right, strand)]
     d_row_of, d_rp = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
@@ -288,8 +288,8 @@ def test_ps_kernel_generations_agree(ctx, n, s):
     d_ps, d_excl = ctx.empty((n, s), np.float32), ctx.empty((n, s), np.int64)
     refs = {}
     try:
-        for kern, reach, q3 in ((2, 1, 0), (0, 1, 0), (0, 0, 0), (1, 1, 0), (1, 0, 0), (2, 1, 1), (0, 1, 1), (1, 1, 1)):
-            ctx.set_param("ps.dma", kern)
+        for kern, reach, q3 in ((1, 1, 0), (0, 1, 0), (0, 0, 0), (1, 1, 1), (0, 1, 1), (0, 0, 1)):
+            ctx.set_param("ps.gen1", kern)
             ctx.set_param("ps.use_reach", reach)
             ctx.set_param("ps.quantize3", q3)
             d_ps.memset(0xff)
@@ -301,7 +301,7 @@ def test_ps_kernel_generations_agree(ctx, n, s):
                 refs[q3] = got
             assert np.array_equal(got[0], refs[q3][0]) and np.array_equal(got[1], refs[q3][1]), (kern, reach, q3)
     finally:
-        ctx.set_param("ps.dma", 0)
+        ctx.set_param("ps.gen1", 0)
         ctx.set_param("ps.use_reach", 1)
         ctx.set_param("ps.quantize3", 0)
     ref = refs[0]
@@ -311,10 +311,16 @@ def test_ps_kernel_generations_agree(ctx, n, s):
     assert np.array_equal(ref[1][:3000][inside], want_excl[inside])
 
 
-@pytest.mark.parametrize("lds,threads,tile_rows,halo", [(8192, 64, 0, -1), (32768, 256, 7, 0), (65536, 1024, 0, 3),
-                                                         (163840, 512, 0, 40), (81920, 1024, 0, 1)])
-def test_ps_launch_shapes(ctx, lds, threads, tile_rows, halo):
-    n, s = 4000, 100
+@pytest.mark.parametrize("lds,threads,tile_rows,halo,s", [
+    (8192, 64, 0, -1, 100), (32768, 256, 7, 0, 100), (65536, 1024, 0, 3, 100), (163840, 512, 0, 40, 100),
+    (81920, 1024, 0, 1, 100),
+    # tile shapes at the limits of the second-generation kernel's register staging (four own-row vectors, two row
+    # pointers per thread): few threads x wide rows, many rows x narrow rows, a forced tile beyond both
+    (81920, 64, 0, -1, 256), (81920, 64, 0, -1, 132), (163840, 128, 0, -1, 200), (81920, 256, 0, -1, 4),
+    (81920, 256, 0, -1, 8), (81920, 64, 0, 16, 8), (81920, 128, 300, -1, 8), (81920, 64, 40, -1, 256),
+    (163840, 1024, 0, -1, 1000), (81920, 192, 0, -1, 520)])
+def test_ps_launch_shapes(ctx, lds, threads, tile_rows, halo, s):
+    n = 4000
     cr, left, right, strand = synth.make_junctions(n, 21, n_chrom=3)
     _, row_ptr, col = O.cluster_csr(cr, left, right, strand)
     counts = synth.make_counts(n, s, 22)

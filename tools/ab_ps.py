@@ -10,7 +10,7 @@ from splicedice_amd.engine import Context
 n, s = int(sys.argv[1]), int(sys.argv[2])
 cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[3:]]
 keys = sorted({k for c in cfgs for k in c})
-DEFAULTS = {"halo_rows": -1, "tile_rows": 0, "chunk_cols": 0, "dma": 0, "use_reach": 1, "nt_loads": 1, "prio": 1, "xcd_remap": 1, "dma_ablate": 0, "quantize3": 0}
+DEFAULTS = {"halo_rows": -1, "tile_rows": 0, "chunk_cols": 0, "gen1": 0, "use_reach": 1, "nt_loads": 1, "prio": 1, "xcd_remap": 1, "quantize3": 0}
 ctx = Context(0)
 cr, l, r, st = synth.make_junctions(n, 2)
 d = [ctx.to_device(x) for x in (cr, l, r, st)]
@@ -43,7 +43,7 @@ for c in cfgs:
         ref = (got, tail)
     else:
         same = np.array_equal(got, ref[0]) and np.array_equal(tail, ref[1])
-        print(f"cfg {c}: {'bit-equal to the first configuration' if same else 'DIFFERS from the first configuration' + (' (ablation: expected)' if c.get('dma_ablate') else '')}", flush=True)
+        print(f"cfg {c}: {'bit-equal to the first configuration' if same else 'DIFFERS from the first configuration'}", flush=True)
 for rep in range(4):
     for c in cfgs:
         apply(c)
