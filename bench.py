@@ -555,11 +555,24 @@ def _tiled_rows(block, lo, hi):
     return np.ascontiguousarray(block[np.arange(lo, hi) % block.shape[0]])
 
 
+def _sharded_setup(world, rank, n_total, seed):
+    """ONE junction set in output row order, cut from the COORDINATES (shard.shard_plan_junctions: no rank clusters the
+    whole set) -> (plan, this rank's part, the coordinates of its rows [ext_lo, ext_hi))"""
+    from splicedice_amd import shard
+    junc = synth.make_junctions(n_total, seed)             # identical on every rank
+    o = shard.junction_order(*junc)
+    junc = tuple(np.ascontiguousarray(x[o]) for x in junc)
+    plan = shard.shard_plan_junctions(*junc, world)
+    part = plan[rank]
+    return plan, part, tuple(np.ascontiguousarray(x[part["ext_lo"]:part["ext_hi"]]) for x in junc)
+
+
 class ShardedPairwiseWorkload:
     """N > 1, `pairwise`: ONE junction set of N x 25 000 junctions x 200 samples (N = 8: BASELINE config 4) cut by the
-    library's shard plan (sdice_shard_plan: clean cuts); every rank holds ITS count rows only.  step = the product's
-    sharded pipeline (distributed.PairwiseShard.step): exclusion sums + Fisher on the rank's rows, device-side packing,
-    RCCL all-to-all (rows -> pair columns), BH down complete columns, all-to-all back, unpack."""
+    library's shard plan (sdice_shard_plan_junctions: clean cuts, from the coordinates); every rank holds ITS count rows
+    only and clusters ITS rows only.  step = the product's sharded pipeline (distributed.PairwiseShard.step): clustering
+    of the rank's range + exclusion sums + Fisher on the rank's rows, device-side packing, RCCL all-to-all (rows -> pair
+    columns), BH down complete columns, all-to-all back, unpack."""
     name = "pairwise, one dataset sharded over the ranks"
     metric = PairwiseWorkload.metric
     unit = PairwiseWorkload.unit
@@ -567,22 +580,18 @@ class ShardedPairwiseWorkload:
     kernel = "fisher_pairs_kernel"
 
     def __init__(self, ctx, dist, world, n, s):
-        from splicedice_amd import distributed, shard
+        from splicedice_amd import distributed
         self.ctx, self.world, self.s = ctx, world, s or 200
         self.n_total = (n or 25_000) * world
         s = self.s
         t = time.time()
-        junc = synth.make_junctions(self.n_total, 4)             # identical on every rank
-        row_of, self.row_ptr, self.col = ctx.cluster(*junc)       # replicated clustering (it is milliseconds)
-        self.plan = shard.shard_plan(self.row_ptr, self.col, world)
-        part = self.plan[dist.rank]
+        self.plan, part, self.jext = _sharded_setup(world, dist.rank, self.n_total, 4)
         blk = synth.make_counts(min(self.n_total, 50_000), s, 40)
         ext = _tiled_rows(blk, part["ext_lo"], part["ext_hi"])
         self.gen_s = time.time() - t
         self.comm, self.comm_note = _device_comm(ctx, dist, world)
         self.shard = distributed.PairwiseShard(ctx, self.comm, self.n_total, s, self.plan, "pairwise", "fisher")
-        rp, cl = shard.local_csr(self.row_ptr, self.col, part)
-        self.shard.load(ext, rp, cl)
+        self.shard.load(ext, junctions=self.jext)
         self.n = part["own_hi"] - part["own_lo"]
         self.pairs = s * (s - 1) // 2
         self.units = self.n * self.pairs
@@ -594,8 +603,9 @@ class ShardedPairwiseWorkload:
 
     def describe(self):
         return {"workload": f"pairwise {self.n_total} junctions x {self.s} samples in total over {self.world} ranks "
-                            f"(BASELINE config 4 is 200k junctions over 8 GPUs), one junction set cut by sdice_shard_plan: "
-                            f"exclusion sums + Fisher + pack + all-to-all + BH per pair column + all-to-all back",
+                            f"(BASELINE config 4 is 200k junctions over 8 GPUs), one junction set cut by sdice_shard_plan_junctions: "
+                            f"cluster (the rank's own range) + exclusion sums + Fisher + pack + all-to-all + BH per pair column + "
+                            f"all-to-all back",
                 "junctions_total": self.n_total, "rows_per_rank": [q["own_hi"] - q["own_lo"] for q in self.plan],
                 "samples": self.s, "collective": self.comm_note or "RCCL all-to-all (grouped send/recv), twice per step",
                 "collectives": self.shard.timed_collectives() if self.comm_note is None else None}
@@ -608,11 +618,10 @@ class ShardedPairwiseWorkload:
                                        "none", "fisher")
         ok = True
         try:
-            from splicedice_amd import shard as _shard
-            rp, cl = _shard.local_csr(self.row_ptr, self.col, self.part)
-            sh.load(self.ext, rp, cl)
+            sh.load(self.ext, junctions=self.jext)
             sh.step()
             p = sh.result()
+            rp, cl, _ = sh.csr_host()
             a0 = self.part["own_lo"] - self.part["ext_lo"]
             m, cols = min(2, self.n), 12
             _, excl = O.calculate_psi_vectorised(self.ext, rp, cl)
@@ -629,10 +638,10 @@ class ShardedPairwiseWorkload:
 
 class ShardedE2EWorkload:
     """N > 1, quant + compare end to end: ONE junction set of N x 625 000 junctions x 1000 samples (N = 8: BASELINE
-    config 5) cut by the library's shard plan.  step = clustering of the whole set (replicated on every rank: it is
-    milliseconds) + the product's sharded pipeline (distributed.CompareShard.step): PS with the '.3f' round
-    trip on the rank's rows, rank-sum into ONE packed per-junction block, ONE RCCL all-gather of that block (29 B per
-    junction), BH over the gathered p-values."""
+    config 5) cut by the library's shard plan (from the coordinates: no rank clusters the whole set).  step = the
+    product's sharded pipeline (distributed.CompareShard.step): clustering of the rank's OWN rows [ext_lo, ext_hi)
+    (asynchronous, per-rank work that shrinks with N), PS with the '.3f' round trip on them, rank-sum into ONE packed
+    per-junction block, ONE RCCL all-gather of that block (37 B per junction), BH over the gathered p-values."""
     name = "quant + compare_sample_sets end to end, one dataset sharded over the ranks"
     metric = QuantWorkload.metric
     unit = QuantWorkload.unit
@@ -640,18 +649,12 @@ class ShardedE2EWorkload:
     kernel = "ranksum_count_kernel"
 
     def __init__(self, ctx, dist, world, n, s):
-        from splicedice_amd import distributed, shard
+        from splicedice_amd import distributed
         self.ctx, self.world, self.s = ctx, world, s or 1000
         self.n_total = (n or 625_000) * world
         s, nt = self.s, self.n_total
         t = time.time()
-        self.junc = synth.make_junctions(nt, 5)
-        self.d_j = [ctx.to_device(x) for x in self.junc]
-        self.d_row_of, self.d_row_ptr = ctx.empty(nt, np.int32), ctx.empty(nt + 1, np.int64)
-        d_col, self.nnz = ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr)
-        row_ptr, col = self.d_row_ptr.to_host(), d_col.to_host()
-        self.plan = shard.shard_plan(row_ptr, col, world)
-        part = self.plan[dist.rank]
+        self.plan, part, jext = _sharded_setup(world, dist.rank, nt, 5)
         blk = synth.make_counts(min(nt, 125_000), s, 20)
         ext = _tiled_rows(blk, part["ext_lo"], part["ext_hi"])
         del blk
@@ -659,27 +662,29 @@ class ShardedE2EWorkload:
         self.g1, self.g2 = np.arange(0, s // 2, dtype=np.int32), np.arange(s // 2, s, dtype=np.int32)
         self.comm, self.comm_note = _device_comm(ctx, dist, world)
         self.shard = distributed.CompareShard(ctx, self.comm, nt, s, self.plan, self.g1, self.g2)
-        rp, cl = shard.local_csr(row_ptr, col, part)
-        self.shard.load(ext, rp, cl)
+        self.shard.load(ext, junctions=jext)
         self.n = part["own_hi"] - part["own_lo"]
         self.units = self.n * s
         self.alg_bytes = (4.0 * s + 28.0) * self.n
         big = max(self.g1.size, self.g2.size)
         self.kernel = ("ranksum_pairq_kernel" if big > 16 and self.g1.size <= 63 else "ranksum_pair_kernel") if big <= 64 else "ranksum_count_kernel" if big <= 1024 else "ranksum_block_kernel"
         self.part = part
-        del ext, row_ptr, col
+        self.nnz_own = None
+        del ext
 
     def step(self):
-        self.ctx.cluster_dev(*self.d_j, self.d_row_of, self.d_row_ptr, sync=False)      # replicated, asynchronous
         self.shard.step()
 
     def describe(self):
         _, block = self.shard.off, self.shard.block
+        if self.nnz_own is None:
+            self.nnz_own = self.shard.csr_host()[2]
+        rows = self.part["ext_hi"] - self.part["ext_lo"]
         return {"workload": f"quant + compare end to end, {self.n_total} junctions x {self.s} samples in total over {self.world} ranks "
-                            f"(BASELINE config 5 is 5M x 1000 over 8 GPUs), one junction set cut by sdice_shard_plan: cluster "
-                            f"(replicated) + PS + quantise + rank-sum + ONE all-gather of the per-junction table + BH",
+                            f"(BASELINE config 5 is 5M x 1000 over 8 GPUs), one junction set cut by sdice_shard_plan_junctions: cluster "
+                            f"(the rank's own range) + PS + quantise + rank-sum + ONE all-gather of the per-junction table + BH",
                 "junctions_total": self.n_total, "rows_per_rank": [q["own_hi"] - q["own_lo"] for q in self.plan],
-                "samples": self.s, "avg_overlap_degree": round(self.nnz / self.n_total, 2),
+                "samples": self.s, "avg_overlap_degree": round(self.nnz_own / max(rows, 1), 2),
                 "collective": self.comm_note or f"ONE RCCL all-gather of {block} B per rank (the packed per-junction table) per step"}
 
     def verify(self):

@@ -298,6 +298,12 @@ int sdice_rowstats_dev(sdice_ctx* ctx, int64_t n, int32_t s, const void* d_data,
  *      plan[world][4] = own_lo, own_hi (rows whose results the rank produces), ext_lo, ext_hi (rows it holds). */
 int sdice_shard_plan(int64_t n, const int64_t* row_ptr, const int32_t* col, int32_t world, double max_shift_frac,
                      int64_t* plan);
+/* the same plan from the junction coordinates alone -- rows in output order, i.e. sorted by (chrom rank, left, right,
+ * strand) and distinct -- so that no rank has to cluster the whole set before it knows its range: i < j of one
+ * (chrom, strand) are joined iff left[j] <= right[i] (SPLICEDICE.py:237-250).  A rank then clusters rows
+ * [ext_lo, ext_hi) alone (sdice_cluster*): the lists of its own rows are complete, indices relative to ext_lo. */
+int sdice_shard_plan_junctions(int64_t n, const int32_t* chrom_rank, const int32_t* left, const int32_t* right,
+                               const int8_t* strand, int32_t world, double max_shift_frac, int64_t* plan);
 
 /* ---- multi-GPU (new; the reference is single-process): one context per rank,
  *      RCCL communicator owned by the context.  id is SDICE_COMM_ID_BYTES opaque

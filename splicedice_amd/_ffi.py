@@ -81,6 +81,7 @@ SIGNATURES = {
     "sdice_rowstats": [ctxp, C.c_int64, C.c_int32, vp, C.c_int, vp, C.c_int32, vp, vp, vp],
     "sdice_rowstats_dev": [ctxp, C.c_int64, C.c_int32, vp, C.c_int, vp, C.c_int32, vp, vp, vp],
     "sdice_shard_plan": [C.c_int64, vp, vp, C.c_int32, C.c_double, vp],
+    "sdice_shard_plan_junctions": [C.c_int64, vp, vp, vp, vp, C.c_int32, C.c_double, vp],
     "sdice_comm_unique_id": [ctxp, vp],
     "sdice_comm_init": [ctxp, vp, C.c_int, C.c_int],
     "sdice_comm_destroy": [ctxp],

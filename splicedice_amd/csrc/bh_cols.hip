@@ -56,6 +56,7 @@ struct BhsArgs {
     int64_t* big_list;      // [8][big_region]: list x holds buckets of the segments with seg mod 8 == x
     int64_t big_region;
     int reg_cap;            // buckets beyond this many values take the in-HBM path (1024; lower in tests)
+    int ablate;             // timing experiments (param bh.ablate; results are wrong when set): 1 no q store, 2 no bucket-id store
 };
 
 __device__ __forceinline__ uint64_t key_of(double v) {
@@ -335,6 +336,147 @@ __device__ __forceinline__ void bucket_in_regs(const BhsArgs& a, const uint64_t*
     }
 }
 
+// ---- key-only network (the default bucket path) --------------------------------------------------------------
+// BH needs no order inside a tie group (all its members end with the group's last, smallest p * m / rank), so the
+// network moves KEYS ONLY -- half the registers and half the exchange traffic of (key, index) pairs -- and every value
+// then finds its rank by a binary search over the sorted keys, which the wave parks in LDS together with the suffix
+// minima (lower bound: the first member of its tie group; the suffix minimum from there is the group's value).
+// Lane exchanges by DPP (xor 1, 2, 4, 8: VALU rate, no LDS crossbar) and the gfx950 lane swaps (xor 16, 32); a swap
+// hands over BOTH operands of the compare-exchange, which is symmetric in them.
+template <int M> __device__ __forceinline__ unsigned dpp_xor(unsigned x) {
+    if (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    if (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
+    if (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);         // row_ror:8
+    // xor 4: banks 1, 3 take lane - 4 (row_ror:4), banks 0, 2 take lane + 4 (row_ror:12)
+    const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xF, 0xA, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x12C, 0xF, 0x5, false);
+}
+// compare-exchange of `key` with lane ^ M: the lane keeps the smaller key iff keep_min
+template <int M> __device__ __forceinline__ uint64_t cx_lane(uint64_t key, bool keep_min) {
+    uint64_t a, b;
+    if (M >= 16) {
+        const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+        if (M == 32) {
+            const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            a = ((uint64_t)rh[0] << 32) | rl[0]; b = ((uint64_t)rh[1] << 32) | rl[1];
+        } else {
+            const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            a = ((uint64_t)rh[0] << 32) | rl[0]; b = ((uint64_t)rh[1] << 32) | rl[1];
+        }
+    } else {
+        a = key;
+        b = ((uint64_t)dpp_xor<M>((unsigned)(key >> 32)) << 32) | dpp_xor<M>((unsigned)key);
+    }
+    return ((a < b) == keep_min) ? a : b;
+}
+// ascending bitonic network over 64 * K keys; key at position lane * K + k
+template <int K>
+__device__ __forceinline__ void wave_bitonic_keys(uint64_t (&key)[K], const int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64 * K; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j >= 1; j >>= 1) {
+            if (j >= K) {
+                const int lm = j / K;
+                const bool lower = (lane & lm) == 0;
+                const bool up = k2 >= 64 * K ? true : (lane & (k2 / K)) == 0;
+                const bool keep_min = lower == up;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (lm == 1) key[k] = cx_lane<1>(key[k], keep_min);
+                    else if (lm == 2) key[k] = cx_lane<2>(key[k], keep_min);
+                    else if (lm == 4) key[k] = cx_lane<4>(key[k], keep_min);
+                    else if (lm == 8) key[k] = cx_lane<8>(key[k], keep_min);
+                    else if (lm == 16) key[k] = cx_lane<16>(key[k], keep_min);
+                    else key[k] = cx_lane<32>(key[k], keep_min);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int kp = k ^ j;
+                    if (kp > k) {
+                        bool up;
+                        if (k2 < K) up = (k & k2) == 0;
+                        else if (k2 >= 64 * K) up = true;
+                        else up = (lane & (k2 / K)) == 0;
+                        const uint64_t x = key[k], y = key[kp];
+                        const bool sw = (y < x) == up;
+                        key[k] = sw ? y : x;
+                        key[kp] = sw ? x : y;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// one bucket of up to 64 * K values by one wave; SK / SQ: this wave's 64 * K words of LDS each
+template <int K>
+__device__ __forceinline__ void bucket_keys_only(const BhsArgs& a, const uint64_t* ks, const uint32_t* is, const double* pd,
+                                                 int n_b, int64_t seg_off, unsigned start, int bucket, int lane,
+                                                 uint64_t* bmin_out, uint64_t* SK, uint64_t* SQ) {
+    uint64_t key[K], sk[K];
+    uint32_t val[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int p = k * 64 + lane;              // coalesced; the starting arrangement is arbitrary anyway
+        key[k] = ~0ull;
+        val[k] = 0u;
+        if (p < n_b) {
+            if (pd) { key[k] = key_of(pd[p]); val[k] = (uint32_t)p; }
+            else { key[k] = __builtin_nontemporal_load(ks + p); val[k] = __builtin_nontemporal_load(is + p); }
+        }
+        sk[k] = key[k];
+    }
+    wave_bitonic_keys<K>(sk, lane);
+    uint64_t s[K];
+    uint64_t run = ~0ull;
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+        const int p = lane * K + k;
+        const uint64_t r = p < n_b ? raw_bits(sk[k], (int64_t)start + p + 1, a.m) : ~0ull;
+        run = r < run ? r : run;
+        s[k] = run;
+    }
+    uint64_t x = run;                              // inclusive suffix minimum over the lanes >= this one
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = shfl_down_u64(x, o);
+        if (lane + o < 64) x = y < x ? y : x;
+    }
+    uint64_t ex = shfl_down_u64(x, 1);
+    if (lane == 63) ex = ~0ull;
+    if (lane == 0) *bmin_out = x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        SK[lane * K + k] = sk[k];
+        SQ[lane * K + k] = s[k] < ex ? s[k] : ex;
+    }
+    // (LDS operations of one wave execute in order: the reads below see the writes above)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lower bound of each own key among the sorted keys: branch-free, K independent chains
+    int pos[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) pos[k] = 0;
+#pragma unroll
+    for (int st = 32 * K; st >= 1; st >>= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) pos[k] += SK[pos[k] + st - 1] < key[k] ? st : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k * 64 + lane < n_b) {
+            if (!(a.ablate & 1)) a.q_cm[seg_off + val[k]] = SQ[pos[k]];
+            if (!(a.ablate & 2)) a.bid_cm[seg_off + val[k]] = (uint16_t)bucket;
+            if (a.ablate & 4) a.q_cm[seg_off + start + k * 64 + lane] = SQ[pos[k]];      // (coalesced instead)
+        }
+    }
+}
+
 // rare: more than 1024 values in one bucket -- its wave sorts it in place in HBM (all-ascending
 // bitonic network: out-of-range partners count as +inf and never move), then walks it from the end
 __device__ void bucket_in_hbm(const BhsArgs& a, uint64_t* ks, uint32_t* is, int n_b, int64_t seg_off, unsigned start,
@@ -422,16 +564,19 @@ __device__ __forceinline__ BucketRef bucket_ref(const BhsArgs& a, int64_t g) {
 // cache line of its 200 KB gets its 16 values from 16 different buckets -- meet in one L2 and leave it as
 // full lines.  (With buckets dealt over all XCDs every L2 wrote its own partial lines: 26.7 GB of write
 // traffic for 5 GB of results.)
+template <int K>
 __global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int blocks_per_seg) {
+    __shared__ uint64_t SK[4][64 * K], SQ[4][64 * K];
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: the bucket's addresses stay in SGPRs)
     const int64_t k = (int64_t)(blockIdx.x >> 3);
     const int64_t seg_x = (k / blocks_per_seg) * 8 + (blockIdx.x & 7);
-    const int b_x = (int)(k % blocks_per_seg) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the bucket's addresses stay in SGPRs)
+    const int b_x = (int)(k % blocks_per_seg) * 4 + wave;
     if (seg_x >= a.segs || b_x >= a.B) return;
     const int64_t g = seg_x * a.B + b_x;
     const BucketRef r = bucket_ref(a, g);
-    if (r.n_b <= 256 && r.n_b <= a.reg_cap) {
-        bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+    if (r.n_b <= 64 * K && r.n_b <= a.reg_cap) {
+        bucket_keys_only<K>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm, SK[wave], SQ[wave]);
     } else if (lane == 0) {
         // (one list per XCD: the big kernel's workgroups keep to the list of "their" segments, so that the scattered
         //  results of a segment still meet in ONE L2 -- a single list in arrival order spread them over all eight)
@@ -1020,6 +1165,7 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
         if (B > MAX_B) B = MAX_B;
     }
     a.B = B;
+    a.ablate = (int)ctx->param("bh.ablate", 0);
     a.reg_cap = (int)std::min<int64_t>(1024, std::max<int64_t>(0, ctx->param("bh.reg_cap", 1024)));
     a.spb = (int)ctx->param("bh.spb", 8);
     if (a.spb < 1) a.spb = 1;
@@ -1067,7 +1213,12 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     const int blocks_per_seg = (int)sd_ceil_div((int64_t)B, (int64_t)4);
     const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * blocks_per_seg;
     SD_ARG(bucket_blocks < ((int64_t)1 << 31), "bh: too many buckets");
-    SD_LAUNCH(ctx, "bhs_bucket_kernel", bhs_bucket_kernel, dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
+    // bh.keys: keys per lane of the main bucket kernel (4: buckets of up to 256 values, 8: up to 512); larger buckets go
+    // to the (key, index) networks of the second kernel
+    if (ctx->param("bh.keys", 4) >= 8)
+        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<8>), dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
+    else
+        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<4>), dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
     // (a multiple of 8 workgroups, at least 8: workgroup w serves the list of XCD w mod 8)
     const int64_t big_blocks = std::max<int64_t>(8, sd_ceil_div(std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4), (int64_t)8) * 8);
     SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel, dim3((unsigned)big_blocks), dim3(256), 0, a);

@@ -113,6 +113,14 @@ class RcclComm:
         self.ctx.allgather_dev(x, recv)
         return recv
 
+    def allgather_into(self, x, recv):
+        self.ctx.allgather_dev(x, recv)
+        return recv
+
+    def alltoall_into(self, x, recv):
+        self.ctx.alltoall_dev(x, recv, x.nbytes // self.world)
+        return recv
+
     def alltoall(self, x):
         """grouped ncclSend/ncclRecv (sdice_alltoall_dev): block q -> rank q over its direct xGMI link"""
         if not _is_dev(x):
@@ -185,14 +193,27 @@ def shard_stats(engine, counts_ext, rp, cl, first, k, g1, g2, pad_to=None):
     return out
 
 
+def _csr_host(sh):
+    """(row_ptr, col, nnz) of the rows [ext_lo, ext_hi) of a shard object as the device holds them (after a step)"""
+    rp = sh.d_rp.to_host()
+    nnz = int(rp[-1])
+    if sh.d_j is not None:
+        nnz, _ = sh.e.cluster_status()               # (resolves the asynchronous clustering: deferred errors surface here)
+    cl = sh.d_cl.offset(0, (nnz,)).to_host() if nnz else np.zeros(0, np.int32)
+    return rp, cl, nnz
+
+
 class CompareShard:
     """One rank's part of quant -> compare_sample_sets, resident in HBM (device engines).
 
-    load() uploads the rank's count rows and its local CSR once; step() is device work only: PS with the '.3f'
-    round trip fused into the store, rank-sum into ONE packed block (stat_layout), ONE all-gather of that block,
-    p / tested made contiguous with two strided copies, Benjamini-Hochberg over the gathered vector
+    load() uploads the rank's count rows and EITHER its local CSR (cut out of a replicated clustering by the caller)
+    OR the coordinates of its rows [ext_lo, ext_hi) -- then step() clusters that range itself (sdice_cluster_dev,
+    asynchronous: no rank ever clusters the whole junction set; the lists of the own rows are complete by the plan's
+    construction, shard.shard_plan_junctions).  step() is device work only: [clustering of the range,] PS with the
+    '.3f' round trip fused into the store, rank-sum into ONE packed block (stat_layout), ONE all-gather of that
+    block, p / tested made contiguous with two strided copies, Benjamini-Hochberg over the gathered vector
     (sdice_bh_masked_dev: padding and untested rows are absent); result() downloads and drops the padding.
-    bench.py --workload e2e --gpus N times exactly this step (plus the replicated clustering)."""
+    bench.py --workload e2e --gpus N times exactly this step."""
 
     def __init__(self, engine, comm, n, s, plan, g1, g2):
         self.e, self.comm, self.n, self.s, self.plan = engine, comm, n, s, plan
@@ -209,33 +230,53 @@ class CompareShard:
         w = comm.world
         self.d_p_all, self.d_t_all = engine.empty(w * self.m, np.float64), engine.empty(w * self.m, np.uint8)
         self.d_q = engine.empty(w * self.m, np.float64)
-        self.recv = None
-        self.d_counts = self.d_rp = self.d_cl = self.d_ps = None
+        self.recv = engine.empty(w * self.block, np.uint8) if w > 1 else None      # (allocated once: step() is malloc-free)
+        self.d_counts = self.d_rp = self.d_cl = self.d_ps = self.d_row_of = None
+        self.d_j = None
 
-    def load(self, counts_ext, rp, cl):
+    def load(self, counts_ext, rp=None, cl=None, junctions=None):
+        """counts_ext: rows [ext_lo, ext_hi); either (rp, cl) -- the local CSR -- or junctions = (chrom_rank, left,
+        right, strand) of those rows in row order"""
         e = self.e
         if self.k:
             self.d_counts = e.to_device(np.ascontiguousarray(counts_ext), np.int32)
-            self.d_rp = e.to_device(rp, np.int64)
-            self.d_cl = e.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
+            rows = self.d_counts.shape[0]
+            if junctions is not None:
+                cr, l, r, st = junctions
+                assert len(cr) == rows, (len(cr), rows)
+                self.d_j = [e.to_device(cr, np.int32), e.to_device(l, np.int32), e.to_device(r, np.int32), e.to_device(st, np.int8)]
+                self.d_row_of, self.d_rp = e.empty(rows, np.int32), e.empty(rows + 1, np.int64)
+            else:
+                self.d_rp = e.to_device(rp, np.int64)
+                self.d_cl = e.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
             self.d_ps = e.empty(self.d_counts.shape, np.float32)
 
     def step(self):
         e, k, m, w = self.e, self.k, self.m, self.comm.world
         if k:
+            d_cl = self.d_cl
+            if self.d_j is not None:                 # the rank's own range, enqueued without a host round trip
+                d_cl, _ = e.cluster_dev(*self.d_j, self.d_row_of, self.d_rp, sync=False)
+                self.d_cl = d_cl                     # (a view of the context's list buffer: not owned)
             e.set_param("ps.quantize3", 1)          # the '.3f' round trip is fused into the PS store
             try:
-                e.ps_dev(self.d_counts, self.d_rp, self.d_cl, None, self.d_ps)
+                e.ps_dev(self.d_counts, self.d_rp, d_cl, None, self.d_ps)
             finally:
                 e.set_param("ps.quantize3", 0)
             first = self.lo - self.elo
             e.ranksum_dev(self.d_ps.offset(first * self.s, (k, self.s)), self.d_g1, self.d_g2,
                           {name: v.offset(0, (k,)) for name, v in self.views.items()})
-        self.recv = self.comm.allgather(self.packed)                  # ONE collective: world x block bytes
+        if w > 1 and hasattr(self.comm, "allgather_into"):
+            self.comm.allgather_into(self.packed, self.recv)          # ONE collective: world x block bytes
+        else:
+            self.recv = self.comm.allgather(self.packed)
         at_p, at_t = self.off["p"][0], self.off["tested"][0]
         e.copy2d_dev(self.d_p_all.ptr, m * 8, self.recv.ptr + at_p, self.block, m * 8, w)      # rank blocks -> one vector
         e.copy2d_dev(self.d_t_all.ptr, m, self.recv.ptr + at_t, self.block, m, w)
         e.bh_masked_dev(self.d_p_all, self.d_t_all, self.d_q)
+
+    def csr_host(self):
+        return _csr_host(self)
 
     def result(self):
         host = unpack_stats_host(self.recv.to_host(), self.m, self.comm.world)
@@ -243,39 +284,56 @@ class CompareShard:
         return host
 
     def free(self):
-        for a in (self.d_counts, self.d_rp, self.d_cl, self.d_ps, self.d_g1, self.d_g2, self.packed, self.d_p_all,
-                  self.d_t_all, self.d_q):
+        recv = self.recv if self.recv is not self.packed else None
+        for a in (self.d_counts, self.d_rp, self.d_cl, self.d_ps, self.d_row_of, self.d_g1, self.d_g2, self.packed, self.d_p_all,
+                  self.d_t_all, self.d_q, recv, *(self.d_j or ())):
             if a is not None:
                 a.free()
 
 
-def quant_compare_sharded(engine, comm, counts_ext, row_ptr, col, g1, g2, plan=None):
+def quant_compare_sharded(engine, comm, counts_ext, row_ptr, col, g1, g2, plan=None, junctions_ext=None):
     """counts_ext: int32 rows [ext_lo, ext_hi) of the count table in output row order -- this rank's
     shard only (shard.shard_plan(row_ptr, col, world)[rank]); CSR over all rows; two column groups.
 
+    junctions_ext = (chrom_rank, left, right, strand) of the rows [ext_lo, ext_hi), in row order: the rank clusters
+    ITS range itself and no global CSR exists anywhere (row_ptr = col = None; plan = shard.shard_plan_junctions(...)
+    is then required) -- the lists of its own rows are complete by the plan's construction.
+
     Returns dict(tested, p, z, corrected, med1, med2, mean1, mean2, delta) for ALL n rows, identical
     on every rank, plus plan.  `engine`: the HIP Context (device path) or a host double with
-    ps / quantize3 / ranksum / bh.  The per-junction table crosses the ranks as ONE packed block in ONE all-gather.
+    ps / quantize3 / ranksum / bh (/ cluster).  The per-junction table crosses the ranks as ONE packed block in ONE all-gather.
     """
-    n = row_ptr.size - 1
-    plan = plan or shard.shard_plan(row_ptr, col, comm.world)
+    if junctions_ext is not None:
+        if plan is None:
+            raise ValueError("junctions_ext needs the plan it was cut by (shard.shard_plan_junctions)")
+        n = plan[-1]["own_hi"]
+    else:
+        n = row_ptr.size - 1
+        plan = plan or shard.shard_plan(row_ptr, col, comm.world)
     part = plan[comm.rank]
     lo, hi, elo = part["own_lo"], part["own_hi"], part["ext_lo"]
     k = hi - lo
     max_rows = max(max(p["own_hi"] - p["own_lo"] for p in plan), 1)
-    rp, cl = shard.local_csr(row_ptr, col, part) if k else (np.zeros(1, np.int64), np.zeros(0, np.int32))
     ext = np.ascontiguousarray(_own_slice(counts_ext, n, part)) if k else counts_ext[:0]
-    if hasattr(engine, "ps_dev") and comm.device:
+    dev = hasattr(engine, "ps_dev")
+    rp = cl = None
+    if k and junctions_ext is None:
+        rp, cl = shard.local_csr(row_ptr, col, part)
+    elif k and not dev:
+        row_of, rp, cl = engine.cluster(*junctions_ext)             # the range alone; rows arrive in row order
+        if not np.array_equal(row_of, np.arange(len(row_of))):
+            raise ValueError("junctions_ext must be in output row order")
+    if dev and comm.device:
         sh = CompareShard(engine, comm, n, ext.shape[1] if k else len(g1) + len(g2), plan, g1, g2)
         try:
-            sh.load(ext, rp, cl)
+            sh.load(ext, rp, cl, junctions=junctions_ext if k else None)
             sh.step()
             engine.sync()
             host = sh.result()
         finally:
             sh.free()
     else:
-        if hasattr(engine, "ps_dev"):
+        if dev:
             raise NotImplementedError("a device engine needs a device communicator (RcclComm / SingleComm)")
         stats = shard_stats(engine, ext, rp, cl, lo - elo, k, g1, g2, pad_to=max_rows)
         gathered = comm.allgather(pack_stats_host(stats, max_rows))             # ONE collective
@@ -360,11 +418,14 @@ def _pairwise_host(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction,
 
 
 class PairwiseShard:
-    """One rank's part of `pairwise`, resident in HBM (device engines): load() uploads the rank's count rows and local
-    CSR once; step() is device work only -- exclusion sums, the per-pair test of the rank's rows, and the correction:
-    "pairwise" packs the p-value matrix into per-rank column blocks ON THE DEVICE (sdice_copy2d_dev), all-to-all,
-    column BH on complete columns, all-to-all back, unpack; "all" all-gathers the raw matrix and ranks it redundantly
-    (sdice_bh_masked_dev); "none" needs no exchange.  bench.py --workload pairwise --gpus N times exactly this step."""
+    """One rank's part of `pairwise`, resident in HBM (device engines): load() uploads the rank's count rows and EITHER
+    its local CSR OR the coordinates of its rows [ext_lo, ext_hi) (step() then clusters that range itself, as
+    CompareShard does) and allocates every exchange buffer ONCE (their shapes follow from the plan); step() is device
+    work only, no allocation, no synchronisation -- exclusion sums, the per-pair test of the rank's rows, and the
+    correction: "pairwise" packs the p-value matrix into per-rank column blocks ON THE DEVICE (sdice_copy2d_dev),
+    all-to-all, column BH on complete columns, all-to-all back, unpack; "all" all-gathers the raw matrix and ranks it
+    redundantly (sdice_bh_masked_dev); "none" needs no exchange.  bench.py --workload pairwise --gpus N times exactly
+    this step."""
 
     def __init__(self, engine, comm, n, s, plan, correction="pairwise", test="fisher"):
         self.e, self.comm, self.n, self.s, self.plan = engine, comm, n, s, plan
@@ -376,24 +437,56 @@ class PairwiseShard:
         self.rows_of = [q["own_hi"] - q["own_lo"] for q in plan]
         self.maxk = max(max(self.rows_of), 1)
         self.d_p = engine.empty((max(self.k, 1), max(self.pairs, 1)), np.float64)
-        self.d_counts = self.d_rp = self.d_cl = self.d_excl = None
+        self.d_counts = self.d_rp = self.d_cl = self.d_excl = self.d_row_of = None
+        self.d_j = None
         self.d_bad = engine.empty(1, np.int64) if test == "chi2" else None
+        self.bufs = {}                                        # exchange buffers, allocated by load()
         self.ms = {}                                          # per-collective times of the last timed_collectives()
 
-    def load(self, counts_ext, rp, cl):
-        e = self.e
+    def load(self, counts_ext, rp=None, cl=None, junctions=None):
+        e, w = self.e, self.comm.world
         if self.k and self.pairs:
             self.d_counts = e.to_device(np.ascontiguousarray(counts_ext), np.int32)
-            self.d_rp = e.to_device(rp, np.int64)
-            self.d_cl = e.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
+            rows = self.d_counts.shape[0]
+            if junctions is not None:
+                cr, l, r, st = junctions
+                assert len(cr) == rows, (len(cr), rows)
+                self.d_j = [e.to_device(cr, np.int32), e.to_device(l, np.int32), e.to_device(r, np.int32), e.to_device(st, np.int8)]
+                self.d_row_of, self.d_rp = e.empty(rows, np.int32), e.empty(rows + 1, np.int64)
+            else:
+                self.d_rp = e.to_device(rp, np.int64)
+                self.d_cl = e.to_device(cl if cl.size else np.zeros(1, np.int32), np.int32)
             self.d_excl = e.empty(self.d_counts.shape, np.int64)
+        if self.pairs and self.correction == "pairwise":
+            ranges = pair_column_ranges(self.pairs, w)
+            maxw = max(max(b - a for a, b in ranges), 1)
+            a, b = ranges[self.comm.rank]
+            shape = (w, self.maxk, maxw)
+            self.bufs = dict(send=e.empty(shape, np.float64).zero(), back=e.empty(shape, np.float64).zero(),
+                             mine=e.empty((max(self.n, 1), max(b - a, 1)), np.float64))
+            if w > 1:
+                self.bufs.update(got=e.empty(shape, np.float64), got2=e.empty(shape, np.float64))
+        elif self.pairs and self.correction == "all":
+            self.bufs = dict(pad=e.empty((self.maxk, self.pairs), np.float64),
+                             d_q=e.empty((w * self.maxk, self.pairs), np.float64))
+            if w > 1:
+                self.bufs["everything"] = e.empty((w * self.maxk, self.pairs), np.float64)
+
+    def _alltoall(self, x, into):
+        if into is not None and hasattr(self.comm, "alltoall_into"):
+            return self.comm.alltoall_into(x, into)
+        return self.comm.alltoall(x)
 
     def step(self):
         e, comm, k, n, s, pairs = self.e, self.comm, self.k, self.n, self.s, self.pairs
         a0, d_p, maxk, rows_of = self.lo - self.elo, self.d_p, self.maxk, self.rows_of
         n_bad = 0
         if k and pairs:
-            e.ps_dev(self.d_counts, self.d_rp, self.d_cl, self.d_excl, None)
+            d_cl = self.d_cl
+            if self.d_j is not None:                          # the rank's own range, enqueued without a host round trip
+                d_cl, _ = e.cluster_dev(*self.d_j, self.d_row_of, self.d_rp, sync=False)
+                self.d_cl = d_cl                              # (a view of the context's list buffer: not owned)
+            e.ps_dev(self.d_counts, self.d_rp, d_cl, self.d_excl, None)
             inc, exc = self.d_counts.offset(a0 * s, (k, s)), self.d_excl.offset(a0 * s, (k, s))
             if self.test == "chi2":
                 e.chi2_pairs_dev(inc, exc, d_p.offset(0, (k, pairs)), self.d_bad)
@@ -406,14 +499,13 @@ class PairwiseShard:
             ranges = pair_column_ranges(pairs, comm.world)
             maxw = max(max(b - a for a, b in ranges), 1)
             blk = maxk * maxw * 8
-            send = e.empty((comm.world, maxk, maxw), np.float64).zero()
+            send, back, mine = self.bufs["send"], self.bufs["back"], self.bufs["mine"]
             for q, (a, b) in enumerate(ranges):               # pack my rows of rank q's columns (device, strided)
                 if k and b > a:
                     e.copy2d_dev(send.ptr + q * blk, maxw * 8, d_p.ptr + a * 8, pairs * 8, (b - a) * 8, k)
-            got = comm.alltoall(send)
+            got = self._alltoall(send, self.bufs.get("got"))
             a, b = ranges[comm.rank]
             w = b - a
-            mine = e.empty((max(n, 1), max(w, 1)), np.float64)
             at = 0
             for r in range(comm.world):                       # rank r's rows of MY columns -> one [n, w] table
                 if rows_of[r] and w:
@@ -421,39 +513,42 @@ class PairwiseShard:
                 at += rows_of[r]
             if n and w:
                 e.bh_columns_dev(mine.offset(0, (n, w)))
-            back, at = e.empty((comm.world, maxk, maxw), np.float64).zero(), 0
+            at = 0
             for r in range(comm.world):
                 if rows_of[r] and w:
                     e.copy2d_dev(back.ptr + r * blk, maxw * 8, mine.ptr + at * w * 8, w * 8, w * 8, rows_of[r])
                 at += rows_of[r]
-            got2 = comm.alltoall(back)
+            got2 = self._alltoall(back, self.bufs.get("got2"))
             for q, (a, b) in enumerate(ranges):               # corrected values back into my rows
                 if k and b > a:
                     e.copy2d_dev(d_p.ptr + a * 8, pairs * 8, got2.ptr + q * blk, maxw * 8, (b - a) * 8, k)
-            self._a2a_bufs = (send, back)                     # (kept for timed_collectives)
         elif self.correction == "all" and pairs > 0:
-            pad = e.empty((maxk, pairs), np.float64).memset(0xBF)     # 0xBFBF... is a negative double: "absent"
+            pad, d_q = self.bufs["pad"].memset(0xBF), self.bufs["d_q"]     # 0xBFBF... is a negative double: "absent"
             if k:
                 e.copy2d_dev(pad.ptr, pairs * 8, d_p.ptr, pairs * 8, pairs * 8, k)
-            everything = comm.allgather(pad)
-            d_q = e.empty(everything.shape, np.float64)
+            if "everything" in self.bufs and hasattr(comm, "allgather_into"):
+                everything = comm.allgather_into(pad, self.bufs["everything"])
+            else:
+                everything = comm.allgather(pad)
             e.bh_masked_dev(everything, None, d_q)
             if k:
                 e.copy2d_dev(d_p.ptr, pairs * 8, d_q.ptr + comm.rank * maxk * pairs * 8, pairs * 8, pairs * 8, k)
 
     def timed_collectives(self, reps=3):
         """ms per all-to-all of the step's block shape, timed alone (after a step)"""
-        bufs = getattr(self, "_a2a_bufs", None)
-        if not bufs:
+        if "send" not in self.bufs:
             return {}
-        e = self.e
-        self.comm.alltoall(bufs[0])
+        e, send = self.e, self.bufs["send"]
+        self._alltoall(send, self.bufs.get("got"))
         e.sync()
         e.timer_start()
         for _ in range(reps):
-            self.comm.alltoall(bufs[0])
+            self._alltoall(send, self.bufs.get("got"))
         ms = e.timer_stop() / reps
-        return {"alltoall_ms": ms, "alltoall_bytes_per_rank": int(bufs[0].nbytes), "alltoalls_per_step": 2}
+        return {"alltoall_ms": ms, "alltoall_bytes_per_rank": int(send.nbytes), "alltoalls_per_step": 2}
+
+    def csr_host(self):
+        return _csr_host(self)
 
     def result(self):
         self.e.sync()
@@ -461,22 +556,25 @@ class PairwiseShard:
         return self.d_p.offset(0, (k, pairs)).to_host() if k and pairs else np.zeros((k, pairs), dtype=np.float64)
 
     def free(self):
-        for a in (self.d_counts, self.d_rp, self.d_cl, self.d_excl, self.d_p, self.d_bad):
+        for a in (self.d_counts, self.d_rp, self.d_cl, self.d_excl, self.d_row_of, self.d_p, self.d_bad, *(self.d_j or ()),
+                  *self.bufs.values()):
             if a is not None:
                 a.free()
+        self.bufs = {}
 
 
-def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, test="fisher"):
+def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, test="fisher", junctions=None):
     sh = PairwiseShard(engine, comm, n, ext.shape[1], plan, correction, test)
     try:
-        sh.load(ext, rp, cl)
+        sh.load(ext, rp, cl, junctions=junctions)
         sh.step()
         return sh.result()
     finally:
         sh.free()
 
 
-def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwise", plan=None, test="fisher"):
+def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwise", plan=None, test="fisher",
+                     junctions_ext=None):
     """`pairwise` with junction rows sharded over ranks.
 
     counts_ext: int32 rows [ext_lo, ext_hi) of this rank's shard in row order; CSR over all rows.
@@ -485,22 +583,38 @@ def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwis
     column over all junctions), "all" (one BH over the whole matrix), "none".  test = "chi2": the Yates-corrected
     chi-square of --chi2 (pairwise_fisher.py:133-136) on the same shards; a table with a zero expected frequency anywhere
     aborts the run on every rank, as the reference's chi2_contingency does.
+    junctions_ext (with plan = shard.shard_plan_junctions(...), row_ptr = col = None): the rank clusters its own rows
+    [ext_lo, ext_hi) itself, as in quant_compare_sharded.
     Returns dict(p=[k, pairs] for this rank's own rows, own=(lo, hi), plan=...).
     """
     if correction not in ("pairwise", "all", "none"):
         raise ValueError("correction must be pairwise | all | none")
     if test not in ("fisher", "chi2"):
         raise ValueError("test must be fisher | chi2")
-    n = row_ptr.size - 1
-    plan = plan or shard.shard_plan(row_ptr, col, comm.world)
+    if junctions_ext is not None:
+        if plan is None:
+            raise ValueError("junctions_ext needs the plan it was cut by (shard.shard_plan_junctions)")
+        n = plan[-1]["own_hi"]
+    else:
+        n = row_ptr.size - 1
+        plan = plan or shard.shard_plan(row_ptr, col, comm.world)
     part = plan[comm.rank]
     lo, hi, elo = part["own_lo"], part["own_hi"], part["ext_lo"]
     k = hi - lo
     ext = np.ascontiguousarray(_own_slice(counts_ext, n, part))
     s = ext.shape[1]
     pairs = s * (s - 1) // 2
-    rp, cl = shard.local_csr(row_ptr, col, part) if k else (np.zeros(1, np.int64), np.zeros(0, np.int32))
     dev = hasattr(engine, "fisher_pairs_dev") and comm.device
-    fn = _pairwise_dev if dev else _pairwise_host
-    p = fn(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction, test)
+    rp, cl = np.zeros(1, np.int64), np.zeros(0, np.int32)
+    if k and junctions_ext is None:
+        rp, cl = shard.local_csr(row_ptr, col, part)
+    elif k and not dev:
+        row_of, rp, cl = engine.cluster(*junctions_ext)
+        if not np.array_equal(row_of, np.arange(len(row_of))):
+            raise ValueError("junctions_ext must be in output row order")
+    if dev:
+        p = _pairwise_dev(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction, test,
+                          junctions=junctions_ext if k else None)
+    else:
+        p = _pairwise_host(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction, test)
     return dict(p=p, own=(lo, hi), plan=plan)

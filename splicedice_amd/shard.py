@@ -45,6 +45,28 @@ def shard_plan(row_ptr, col, world, max_shift_frac=0.02):
     return [dict(own_lo=int(a), own_hi=int(b), ext_lo=int(c), ext_hi=int(d)) for a, b, c, d in out]
 
 
+def junction_order(chrom_rank, left, right, strand):
+    """permutation that puts junctions into output row order (chrom, left, right, strand) -- SPLICEDICE.py:96"""
+    return np.lexsort((strand, right, left, chrom_rank))
+
+
+def shard_plan_junctions(chrom_rank, left, right, strand, world, max_shift_frac=0.02):
+    """shard_plan from the coordinates of the junctions IN OUTPUT ROW ORDER (sorted, distinct) -- no CSR, so no rank
+    clusters the whole set: a rank clusters its rows [ext_lo, ext_hi) alone and gets the lists of its own rows complete
+    (sdice_shard_plan_junctions, host C++)."""
+    import ctypes as C
+    from . import _ffi
+    cr, l, r = (np.ascontiguousarray(x, dtype=np.int32) for x in (chrom_rank, left, right))
+    st = np.ascontiguousarray(strand, dtype=np.int8)
+    n = cr.size
+    out = np.zeros((world, 4), dtype=np.int64)
+    vp = C.c_void_p
+    _ffi.check(_ffi.load().sdice_shard_plan_junctions(n, cr.ctypes.data_as(vp), l.ctypes.data_as(vp), r.ctypes.data_as(vp),
+                                                      st.ctypes.data_as(vp), int(world), float(max_shift_frac),
+                                                      out.ctypes.data_as(vp)), "sdice_shard_plan_junctions")
+    return [dict(own_lo=int(a), own_hi=int(b), ext_lo=int(c), ext_hi=int(d)) for a, b, c, d in out]
+
+
 def local_csr(row_ptr, col, part):
     """CSR of the rows [ext_lo, ext_hi) with neighbour indices relative to ext_lo.
 

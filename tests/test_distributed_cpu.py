@@ -47,11 +47,25 @@ class OracleEngine:
     def bh(self, p):
         return O.bh_fdr(p)
 
+    def cluster(self, cr, l, r, st):
+        return O.cluster_csr(cr, l, r, st)
 
-def _problem():
+
+def _junction_problem(kw=None):
+    """the same junction set as _problem, in output row order, with its counts: what a rank that clusters ITS OWN
+    range works from (no global CSR anywhere)"""
+    from splicedice_amd import shard, synth
+    n, s = 1200, 16
+    cr, l, r, st = synth.make_junctions(n, 17, **(kw or dict(n_chrom=3)))
+    o = shard.junction_order(cr, l, r, st)
+    counts, _, _, g1, g2 = _problem(kw)
+    return tuple(x[o] for x in (cr, l, r, st)), counts, g1, g2
+
+
+def _problem(kw=None):
     from splicedice_amd import synth
     n, s = 1200, 16
-    cr, l, r, st = synth.make_junctions(n, 17, n_chrom=3)
+    cr, l, r, st = synth.make_junctions(n, 17, **(kw or dict(n_chrom=3)))
     row_of, row_ptr, col = O.cluster_csr(cr, l, r, st)
     counts_in = synth.make_counts(n, s, 18, mean=12)
     counts = np.zeros_like(counts_in)
@@ -75,7 +89,19 @@ def _worker(rank, world, port, q):
         mine = counts[part["ext_lo"]:part["ext_hi"]].copy()      # a rank is handed ITS rows only
         del counts
         out = distributed.quant_compare_sharded(OracleEngine(), comm, mine, row_ptr, col, g1, g2)
-        q.put((rank, {k: v for k, v in out.items() if k != "plan"}, out["plan"]))
+        # the same run with every rank clustering ITS OWN range from the junction coordinates (no global CSR): dense
+        # junctions so that the cuts are not clean and the shards carry halos
+        res2 = {}
+        for tag, kw in (("genes", None), ("dense", dict(n_chrom=2, gene_spacing=300, len_span=60000))):
+            junc, counts2, g1, g2 = _junction_problem(kw)
+            plan2 = shard.shard_plan_junctions(*junc, world)
+            a, b = plan2[rank]["ext_lo"], plan2[rank]["ext_hi"]
+            o2 = distributed.quant_compare_sharded(OracleEngine(), comm, counts2[a:b].copy(), None, None, g1, g2, plan=plan2,
+                                                   junctions_ext=tuple(x[a:b] for x in junc))
+            pw = distributed.pairwise_sharded(OracleEngine(), comm, counts2[a:b, :5].copy(), None, None, "pairwise", plan=plan2,
+                                              junctions_ext=tuple(x[a:b] for x in junc))
+            res2[tag] = ({k: v for k, v in o2.items() if k != "plan"}, plan2, pw["own"], pw["p"])
+        q.put((rank, {k: v for k, v in out.items() if k != "plan"}, out["plan"], res2))
     finally:
         dist.destroy_process_group()
 
@@ -84,7 +110,7 @@ def _worker(rank, world, port, q):
 @pytest.mark.parametrize("world", [2])
 def test_sharded_pipeline_equals_single_process(world):
     import torch.multiprocessing as mp
-    from splicedice_amd import distributed
+    from splicedice_amd import distributed, shard
     counts, row_ptr, col, g1, g2 = _problem()
     single = distributed.quant_compare_sharded(OracleEngine(), distributed.SingleComm(), counts, row_ptr, col, g1, g2)
     with socket.socket() as s:
@@ -100,10 +126,24 @@ def test_sharded_pipeline_equals_single_process(world):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == list(range(world))
-    for rank, out, plan in results:
+    keys = ("tested", "p", "z", "corrected", "med1", "med2", "mean1", "mean2", "delta")
+    singles = {}
+    for tag, kw in (("genes", None), ("dense", dict(n_chrom=2, gene_spacing=300, len_span=60000))):
+        c2, rp2, col2, g1b, g2b = _problem(kw)
+        one = distributed.quant_compare_sharded(OracleEngine(), distributed.SingleComm(), c2, rp2, col2, g1b, g2b)
+        _, excl2 = O.calculate_psi_vectorised(c2[:, :5], rp2, col2)
+        singles[tag] = (one, shard.shard_plan(rp2, col2, world), O.bh_columns(O.fisher_pairs(c2[:, :5], excl2)))
+    assert any(p["ext_lo"] < p["own_lo"] or p["ext_hi"] > p["own_hi"] for p in singles["dense"][1])      # halos are exercised
+    for rank, out, plan, res2 in results:
         assert len(plan) == world and plan[0]["own_hi"] > 0
-        for k in ("tested", "p", "z", "corrected", "med1", "med2", "mean1", "mean2", "delta"):
+        for k in keys:
             assert np.array_equal(out[k], single[k]), (rank, k)
+        for tag, (o2, plan2, own, pw) in res2.items():
+            one, plan_csr, pw_want = singles[tag]
+            assert plan2 == plan_csr, (rank, tag)                    # the coordinate plan IS the CSR plan
+            for k in keys:
+                assert np.array_equal(o2[k], one[k]), (rank, tag, k)  # own-range clustering == replicated clustering
+            assert np.array_equal(pw, pw_want[own[0]:own[1]]), (rank, tag)
     assert single["tested"].sum() > 500 and (single["corrected"][single["tested"] == 1] >= single["p"][single["tested"] == 1]).all()
 
 

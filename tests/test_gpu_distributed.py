@@ -56,6 +56,56 @@ def test_sharded_pipeline_on_engine_matches_oracle(ctx):
         assert np.array_equal(st["med1"][tt], want["med1"][sl][tt]) and np.array_equal(st["mean2"][tt], want["mean2"][sl][tt])
 
 
+@pytest.mark.parametrize("kw", [dict(n_chrom=3), dict(n_chrom=2, gene_spacing=300, len_span=60000)])
+def test_own_range_clustering_equals_replicated_clustering(ctx, kw):
+    """every shard of a 3-way plan made from the junction COORDINATES (no CSR): the device pipelines cluster rows
+    [ext_lo, ext_hi) themselves (sdice_cluster_dev inside the step) and reproduce, bit for bit, what the same pipelines
+    give on the local CSR cut out of a clustering of the whole set -- quant -> compare and pairwise (dense junctions:
+    shards with halos)"""
+    from splicedice_amd import distributed, shard, synth
+    n, s = 6000, 24
+    cr, l, r, st = synth.make_junctions(n, 91, **kw)
+    o = shard.junction_order(cr, l, r, st)
+    junc = tuple(x[o] for x in (cr, l, r, st))
+    row_of, row_ptr, col = ctx.cluster(*junc)
+    assert np.array_equal(row_of, np.arange(n))
+    counts = synth.make_counts(n, s, 92, mean=12)
+    g1, g2 = np.arange(0, 12, dtype=np.int32), np.arange(12, 24, dtype=np.int32)
+    plan = shard.shard_plan_junctions(*junc, 3)
+    assert plan == shard.shard_plan(row_ptr, col, 3)
+    halos = 0
+    for part in plan:
+        a, b = part["ext_lo"], part["ext_hi"]
+        halos += (a < part["own_lo"]) + (b > part["own_hi"])
+        ext, jext = np.ascontiguousarray(counts[a:b]), tuple(x[a:b] for x in junc)
+        rp, cl = shard.local_csr(row_ptr, col, part)
+        got = {}
+        for mode in ("csr", "junctions"):
+            sh = distributed.CompareShard(ctx, distributed.SingleComm(), n, s, [part], g1, g2)
+            try:
+                sh.load(ext, rp, cl) if mode == "csr" else sh.load(ext, junctions=jext)
+                sh.step()
+                sh.step()                                           # (a second step re-clusters into the same buffers)
+                ctx.sync()
+                got[mode] = sh.result()
+            finally:
+                sh.free()
+        for k, v in got["csr"].items():
+            assert np.array_equal(v, got["junctions"][k], equal_nan=True), k
+        pw = {}
+        for mode in ("csr", "junctions"):
+            sh = distributed.PairwiseShard(ctx, distributed.SingleComm(), n, 8, [part], "pairwise", "fisher")
+            try:
+                e8 = np.ascontiguousarray(ext[:, :8])
+                sh.load(e8, rp, cl) if mode == "csr" else sh.load(e8, junctions=jext)
+                sh.step()
+                pw[mode] = sh.result()
+            finally:
+                sh.free()
+        assert np.array_equal(pw["csr"], pw["junctions"])
+    assert ("gene_spacing" not in kw) or halos > 0
+
+
 def test_rccl_world1_allgather():
     """own context: the communicator lives and dies with it"""
     from splicedice_amd.engine import Context

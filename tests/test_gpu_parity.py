@@ -788,6 +788,13 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
         ctx.bh_columns_dev(d)
         fast = d.to_host()
         assert np.array_equal(generic, fast, equal_nan=True)
+        ctx.set_param("bh.keys", 8)                                           # eight keys per lane in the main bucket kernel
+        ctx.set_param("bh.mean", 400)
+        d = ctx.to_device(p)
+        ctx.bh_columns_dev(d)
+        assert np.array_equal(generic, d.to_host(), equal_nan=True)
+        ctx.set_param("bh.keys", 4)
+        ctx.set_param("bh.mean", 200)
         if n > 2000:
             ctx.set_param("bh.reg_cap", 64)                                   # most buckets through the in-HBM path
             d = ctx.to_device(p)
@@ -796,6 +803,8 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
     finally:
         ctx.set_param("bh.columns_path", 0)
         ctx.set_param("bh.reg_cap", 1024)
+        ctx.set_param("bh.keys", 4)
+        ctx.set_param("bh.mean", 200)
     ok = ~np.isnan(p).any(axis=0)
     np.testing.assert_allclose(fast[:, ok], O.bh_columns(p[:, ok]), rtol=1e-14, atol=0)
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event times of sdice_bh_columns_dev in one process: prof_bh.py n cols [param=value,...] ..."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from splicedice_amd.engine import Context
+n, cols = int(sys.argv[1]), int(sys.argv[2])
+cfgs = sys.argv[3:] or [""]
+ctx = Context(0)
+rng = np.random.default_rng(1)
+blk = rng.random((min(n, 2000), cols)) ** 2
+blk[rng.random(blk.shape) < 0.2] = 1.0
+d_src = ctx.empty((n, cols), np.float64)
+for a in range(0, n, blk.shape[0]):
+    b = min(n, a + blk.shape[0])
+    d_src.offset(a * cols, (b - a, cols)).upload(np.roll(blk[: b - a], a, axis=1))
+d = ctx.empty((n, cols), np.float64)
+for c in cfgs:
+    kv = [x.split("=") for x in c.split(",") if x]
+    for k, v in kv:
+        ctx.set_param(k, int(v))
+    for it in range(2):
+        ctx.copy2d_dev(d.ptr, cols * 8, d_src.ptr, cols * 8, cols * 8, n)
+        ctx.bh_columns_dev(d)
+    ctx.sync()
+    ctx.prof_enable(1)
+    ctx.prof_reset()
+    reps = 3
+    for it in range(reps):
+        ctx.copy2d_dev(d.ptr, cols * 8, d_src.ptr, cols * 8, cols * 8, n)
+        ctx.bh_columns_dev(d)
+    ctx.sync()
+    rep = ctx.prof_report()
+    ctx.prof_enable(0)
+    for k, v in kv:
+        ctx.set_param(k, {"bh.reg_cap": 1024, "bh.mean": 200, "bh.spb": 8, "bh.keys": 4}.get(k, 0))
+    tot = sum(ms for _, ms in rep.values()) / reps
+    print(f"[{c}] total {tot:.3f} ms: " + ", ".join(f"{name} {ms / reps:.3f}" for name, (cnt, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])), flush=True)
