@@ -61,8 +61,9 @@ from splicedice_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: measured float4-copy ceiling (SURVEY 8(d) asks for both denominators)
-F64_WAVE_INSTS_PER_S = 5.25e11   # measured f64 FMA issue rate (tools/mb/microbench.hip: 33.6e12 lane-FMAs/s over 1024 SIMDs)
-F64_WAVE_INSTS_SPEC = 6.14e11    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 instruction (the guide's clock; the chip holds less under load)
+VALU_WAVE_INSTS_SPEC = 6.14e11   # 1024 SIMDs x 2.4 GHz (the guide's peak engine clock) / 4 cycles per wave64 VALU instruction, f64 included.
+                                 # It is a ceiling on paper: under load the chip holds a lower clock, so no kernel reaches 1.0 of it (a dependent
+                                 # f64 FMA loop, tools/mb/microbench.hip, measured 0.85; that loop is NOT a ceiling and is no longer quoted)
 
 
 def parse_args():
@@ -207,11 +208,11 @@ class QuantWorkload:
         """PS of the first rows against the oracle (same CSR prefix, vectorised restatement)."""
         from oracle import oracle_np as O
         big = self.sample_counts.shape[0]            # rows whose counts are kept on the host
-        rp = self.d_row_ptr.to_host()[: big + 1]
-        col = self.d_col.to_host()[: int(rp[-1])]
+        rp = self.d_row_ptr.offset(0, (big + 1,)).to_host()
+        col = self.d_col.offset(0, (int(rp[-1]),)).to_host()
         inside = np.minimum.reduceat(np.r_[col, 0] < big, np.minimum(rp[:-1], col.size)) | (np.diff(rp) == 0)
         want, _ = O.calculate_psi_vectorised(self.sample_counts, rp, np.minimum(col, big - 1))
-        got = self.d_ps.to_host()[:big]
+        got = self.d_ps.offset(0, (big, self.s)).to_host()
         rows = np.flatnonzero(inside)[:50_000]       # rows with every neighbour among the kept rows
         return bool(np.array_equal(got[rows], want[rows], equal_nan=True)), int(rows.size)
 
@@ -415,20 +416,30 @@ class PairwiseWorkload:
         m = 2
         cols = 12
         self.ctx.fisher_pairs_dev(self.d_counts, self.d_excl, self.d_p)     # raw p-values again (d_p holds BH output)
-        excl = self.d_excl.to_host()[:m, :cols]
+        excl = self.d_excl.offset(0, (m, self.s)).to_host()[:, :cols]
         want = O.fisher_pairs(self.counts[:m, :cols], excl)
-        p = self.d_p.to_host()[:m]
+        p = self.d_p.offset(0, (m, self.pairs)).to_host()
         idx = [i * self.s - i * (i + 1) // 2 + (j - i - 1) for i in range(cols - 1) for j in range(i + 1, cols)]
         ok = np.allclose(p[:, idx], want, rtol=1e-9, atol=0)
         _, want_excl = O.calculate_psi_vectorised(self.counts, self.row_ptr, self.col)
         ok = ok and np.array_equal(self.d_excl.to_host(), want_excl)
-        return bool(ok), m * len(idx)
+        # the corrected table (the step's output): BH of a few whole columns against the restated definition
+        raw_cols = {}
+        for c in (0, self.pairs // 2, self.pairs - 1):
+            one = self.ctx.empty((self.n,), np.float64)
+            self.ctx.copy2d_dev(one.ptr, 8, self.d_p.ptr + c * 8, self.pairs * 8, 8, self.n)
+            raw_cols[c] = (one, one.to_host())
+        self.ctx.bh_columns_dev(self.d_p)
+        for c, (one, raw) in raw_cols.items():
+            self.ctx.copy2d_dev(one.ptr, 8, self.d_p.ptr + c * 8, self.pairs * 8, 8, self.n)
+            ok = ok and bool(np.allclose(one.to_host(), O.bh_fdr(raw), rtol=1e-12, atol=0))
+        return bool(ok), m * len(idx) + 3 * self.n
 
     def cpu_baseline(self, sample):
         from oracle import oracle_np as O
         m = sample or 20             # ~8 s of single-core work
         cols = 60
-        excl = self.d_excl.to_host()[:m, :cols]
+        excl = self.d_excl.offset(0, (m, self.s)).to_host()[:, :cols]
         t = time.time()
         O.fisher_pairs(self.counts[:m, :cols], excl)
         dt = time.time() - t
@@ -484,15 +495,15 @@ class E2EWorkload(QuantWorkload):
         m = 300
         ps = self.d_ps.offset(0, (m, self.s)).to_host()
         want = O.compare_rows(ps, self.g1, self.g2)          # the device's own quantised PS rows
-        got = {k: v.to_host()[:m] for k, v in self.out.items()}
+        got = {k: v.offset(0, (m,)).to_host() for k, v in self.out.items()}
         t = want["tested"].astype(bool)
         ok = np.array_equal(got["tested"], want["tested"]) and np.array_equal(got["z"][t], want["z"][t]) \
             and np.allclose(got["p"][t], want["p"][t], rtol=1e-9, atol=0) \
             and all(np.array_equal(got[k][t], want[k][t]) for k in ("med1", "med2", "mean1", "mean2", "delta"))
         # and the PS rows themselves: quantised oracle PS of rows whose neighbours are all kept on the host
         big = min(self.sample_counts.shape[0], 4000)
-        rp = self.d_row_ptr.to_host()[: big + 1]
-        col = self.d_col.to_host()[: int(rp[-1])]
+        rp = self.d_row_ptr.offset(0, (big + 1,)).to_host()
+        col = self.d_col.offset(0, (int(rp[-1]),)).to_host()
         inside = np.minimum.reduceat(np.r_[col, 0] < big, np.minimum(rp[:-1], col.size)) | (np.diff(rp) == 0)
         rows = np.flatnonzero(inside[:m])
         want_ps, _ = O.calculate_psi_vectorised(self.sample_counts[:big], rp, np.minimum(col, big - 1))
@@ -812,8 +823,8 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
         # every trip), so the hardware's active-lane count says nothing; the kernel counts its own lane-steps in one
         # extra launch outside the timed region (fisher.count_steps): issued, and those that advanced a live walk
         # inside its support.
-        vf = {"peak": F64_WAVE_INSTS_SPEC, "unit": "wave64 VALU instructions/s (all VALU, f64 and not)",
-              "peak_measured_fma_loop": F64_WAVE_INSTS_PER_S}
+        vf = {"peak": VALU_WAVE_INSTS_SPEC, "unit": "wave64 VALU instructions/s (all VALU, f64 and not)",
+              "peak_assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
         try:
             if not all(hasattr(wl, a) for a in ("d_counts", "d_excl", "d_p")):
                 raise AttributeError("lane-step counts are taken on the unsharded workload (N = 1)")
@@ -824,7 +835,9 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
             vf.update({"lane_steps_issued": issued, "lane_steps_useful": useful, "useful_lane_frac": useful / max(issued, 1),
                        "useful_steps_per_pair": useful / (wl.n * (wl.s * (wl.s - 1) // 2)),
                        "valu_per_step": 10, "step_valu_rate": issued / 64 * 10 / (avg_ms * 1e-3),
-                       "step_valu_frac_of_peak": issued / 64 * 10 / (avg_ms * 1e-3) / F64_WAVE_INSTS_SPEC})
+                       "step_valu_frac_of_peak": issued / 64 * 10 / (avg_ms * 1e-3) / VALU_WAVE_INSTS_SPEC,
+                       # ONE number: the share of the chip's peak VALU issue that advances a live walk inside its support
+                       "useful_issue_frac": useful / 64 * 10 / (avg_ms * 1e-3) / VALU_WAVE_INSTS_SPEC})
         except Exception as e:                                  # noqa: BLE001 (a measurement aid must not fail the line)
             ctx.set_param("fisher.count_steps", 0)
             vf["lane_steps_note"] = str(e)
@@ -833,7 +846,7 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
                 pv = json.load(fh)
             if pv["n"] == wl.n and pv["s"] == wl.s:
                 rate = pv["SQ_INSTS_VALU_per_launch"] / (avg_ms * 1e-3)
-                vf.update({"achieved": rate, "frac": rate / F64_WAVE_INSTS_SPEC, "frac_of_measured": rate / F64_WAVE_INSTS_PER_S,
+                vf.update({"achieved": rate, "frac": rate / VALU_WAVE_INSTS_SPEC,
                            "stale": pv.get("src_sha16") != kernel_source_sha16("pairwise"), "source": pv["source"]})
         except (OSError, ValueError, KeyError):
             pass
@@ -842,6 +855,22 @@ def measure(ctx, wl, dist, steps, warmup, gpus, verify=True):
     if verify:
         ok, checked = wl.verify()
         v = {"ok": ok, "checked": checked}
+    if wl.key in ("quant", "e2e") and launches and hasattr(wl, "d_counts") and hasattr(wl, "d_ps") and hasattr(wl, "sample_counts"):
+        # host <-> device rates of this workload's tables (pageable numpy buffers, as the host entry points
+        # of the C ABI receive them), measured apart from the timed region and never part of `value`
+        try:
+            blk = wl.sample_counts
+            view_in = wl.d_counts.offset(0, blk.shape)
+            view_in.upload(blk)
+            t0 = time.perf_counter(); view_in.upload(blk); h2d = time.perf_counter() - t0
+            view_out = wl.d_ps.offset(0, blk.shape)
+            view_out.to_host()
+            t0 = time.perf_counter(); view_out.to_host(); d2h = time.perf_counter() - t0
+            roofline["pcie"] = {"bytes": int(blk.nbytes), "h2d_GBps": blk.nbytes / h2d / 1e9, "d2h_GBps": blk.nbytes / d2h / 1e9,
+                                "note": "count rows in / PS rows out through sdice_h2d / sdice_d2h, pageable host memory; "
+                                        "reported beside the device-resident figures, never inside them"}
+        except Exception as e:                       # noqa: BLE001
+            roofline["pcie"] = {"error": str(e)[:120]}
     if wl.key == "quant" and launches and hasattr(wl, "d_counts") and hasattr(wl, "d_ps"):
         # what a device-to-device copy of the same byte volume (count table -> PS table) takes on THIS box, measured after
         # the timed region and the verification (it overwrites the PS table): the bandwidth ceiling the PS kernel can be held against besides the spec figure
@@ -868,6 +897,8 @@ ALSO = [
     ("compare_c3", "compare", 1_000_000, 100, 200_000, 30, 30_000),        # BASELINE config 3
     ("pairwise_c4_shard", "pairwise", 25_000, 200, 0, 4, 10),              # config 4, one GPU's shard of 8
     ("e2e_c5_shard", "e2e", 625_000, 1000, 125_000, 10, 12_000),            # config 5, one GPU's shard of 8
+    ("pairwise_c4_full", "pairwise", 200_000, 200, 0, 2, 0),                # config 4 at its FULL size on one GPU (no CPU leg: the shard's stands)
+    ("e2e_c5_full", "e2e", 5_000_000, 1000, 125_000, 3, 0),                 # config 5 at its FULL size on one GPU
 ]
 
 
@@ -981,11 +1012,14 @@ def main():
                 rec = {"metric": w.metric, "value": w.units * steps / el, "unit": w.unit, "steps": steps, "warmup": 5,
                        "ms_per_step": el / steps * 1e3, "dtype": w.dtype, "config": w.describe(), "roofline": rl,
                        "verify": vf, "gen_seconds": round(w.gen_s, 1)}
-                if not args.no_cpu_baseline:
+                if not args.no_cpu_baseline and cpu_sample:
                     rec["cpu_baseline"] = w.cpu_baseline(cpu_sample)
                     rec["cpu_baseline"]["real_reference_over_port"] = reference_over_port(kind)
                 failed = failed or bool(vf and not vf["ok"])
                 del w
+                import gc
+                gc.collect()
+                ctx.trim()                       # the scratch of a 32 GB column BH does not stay with the next record
             except Exception as e:      # an extra record must not take the headline down; it is reported as failed
                 rec = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 failed = True

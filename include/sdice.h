@@ -202,6 +202,12 @@ int sdice_bh_masked_dev(sdice_ctx* ctx, int64_t n, const double* d_p, const uint
  * (pairwise_fisher.py:187-191) */
 int sdice_bh_columns(sdice_ctx* ctx, int64_t n, int64_t cols, double* p_inout);
 int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout);
+/* the same for a table whose rows are `pitch` elements apart (a column range of a wider table), pitch >= cols */
+int sdice_bh_columns_pitched_dev(sdice_ctx* ctx, int64_t n, int64_t cols, int64_t pitch, double* d_p_inout);
+
+/* measurement aid (tools/bench_cli.py): out3 = seconds spent formatting, seconds spent writing, bytes written by
+ * sdice_write_table on the calling thread since the last reset */
+int sdice_textio_stats(double* out3, int reset);
 
 /* ---- host-side table text I/O (no device, no context): multithreaded, byte-compatible with the
  *      reference's writers  f'{x:.3f}' (SPLICEDICE.py:353, counts_to_ps.py:69), f'{x:.0f}'
@@ -312,6 +318,11 @@ int sdice_shard_plan_junctions(int64_t n, const int32_t* chrom_rank, const int32
 int sdice_comm_unique_id(sdice_ctx* ctx, void* id_out);
 int sdice_comm_init(sdice_ctx* ctx, const void* id, int rank, int world);
 int sdice_comm_destroy(sdice_ctx* ctx);
+/* collectives beside compute: after sdice_comm_fork the context's collectives run on a second stream, behind everything
+ * enqueued on the main stream so far (call it again before a collective whose input has just been produced);
+ * sdice_comm_join makes the main stream wait for them and takes collectives back to the main stream (sdice_sync joins) */
+int sdice_comm_fork(sdice_ctx* ctx);
+int sdice_comm_join(sdice_ctx* ctx);
 /* all-gather equal-sized row shards: recv holds world * bytes_per_rank */
 int sdice_allgather_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
 /* All-to-all of equal blocks: block q of d_send (bytes_per_peer each) goes to rank q, block r of

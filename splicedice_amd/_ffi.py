@@ -61,6 +61,8 @@ SIGNATURES = {
     "sdice_bh_masked_dev": [ctxp, C.c_int64, vp, vp, vp],
     "sdice_bh_columns": [ctxp, C.c_int64, C.c_int64, vp],
     "sdice_bh_columns_dev": [ctxp, C.c_int64, C.c_int64, vp],
+    "sdice_bh_columns_pitched_dev": [ctxp, C.c_int64, C.c_int64, C.c_int64, vp],
+    "sdice_textio_stats": [vp, C.c_int],
     "sdice_write_table": [C.c_char_p, C.c_char_p, C.c_int64, C.c_int32, vp, vp, vp, C.c_int, C.c_int, C.c_int],
     "sdice_write_clusters": [C.c_char_p, C.c_int64, vp, vp, vp, vp, C.c_int],
     "sdice_write_columns_sfx": [C.c_char_p, C.c_char_p, C.c_int64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_int],
@@ -85,6 +87,8 @@ SIGNATURES = {
     "sdice_comm_unique_id": [ctxp, vp],
     "sdice_comm_init": [ctxp, vp, C.c_int, C.c_int],
     "sdice_comm_destroy": [ctxp],
+    "sdice_comm_fork": [ctxp],
+    "sdice_comm_join": [ctxp],
     "sdice_allgather_dev": [ctxp, vp, vp, C.c_int64],
     "sdice_alltoall_dev": [ctxp, vp, vp, C.c_int64],
     "sdice_copy2d_dev": [ctxp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64],

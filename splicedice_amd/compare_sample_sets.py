@@ -111,8 +111,37 @@ def annotation_suffixes(names, gtf_path):
             "\t" + ",".join(transcript_ids.get(j, nan)) for n, j in enumerate(junctions)]
 
 
+def compare_dev(matrix, g1_idx, g2_idx, ctx):
+    """compare() on the HIP engine stage by stage: table up, rank-sum + BH over the tested rows on resident vectors,
+    per-row results down (sdice_ranksum + sdice_bh do the same steps inside two host calls)"""
+    from . import _stages
+    n = matrix.shape[0]
+    f32 = ("med1", "med2", "mean1", "mean2", "delta")
+    with _stages.stage("h2d"):
+        d_ps = ctx.to_device(matrix, np.float32)
+        d_g1, d_g2 = ctx.to_device(g1_idx, np.int32), ctx.to_device(g2_idx, np.int32)
+        out = dict(tested=ctx.empty(n, np.uint8), p=ctx.empty(n, np.float64), z=ctx.empty(n, np.float64),
+                   **{k: ctx.empty(n, np.float32) for k in f32})
+        d_q = ctx.empty(n, np.float64)
+    with _stages.stage("kernels"):
+        ctx.ranksum_dev(d_ps, d_g1, d_g2, out)
+        ctx.bh_masked_dev(out["p"], out["tested"], d_q)
+        ctx.sync()
+    with _stages.stage("d2h"):
+        res = {k: v.to_host() for k, v in out.items()}
+        q = d_q.to_host()
+    for a in (d_ps, d_g1, d_g2, d_q, *out.values()):
+        a.free()
+    keep = np.flatnonzero(res["tested"])
+    r = {k: res[k][keep] for k in ("p",) + f32}
+    r["corrected"] = q[keep]
+    return keep, r
+
+
 def compare(matrix, g1_idx, g2_idx, ctx):
     """-> (kept row indices, dict of compacted per-row results incl. BH-corrected p)."""
+    if hasattr(ctx, "ranksum_dev") and matrix.shape[0]:
+        return compare_dev(matrix, g1_idx, g2_idx, ctx)
     res = ctx.ranksum(matrix, g1_idx, g2_idx)
     keep = np.flatnonzero(res["tested"])
     out = {k: res[k][keep] for k in ("p", "med1", "med2", "mean1", "mean2", "delta")}
@@ -162,7 +191,9 @@ def run_with(args, ctx=None):
         print("Cannot conduct wilcoxon with less than 3 samples in either group. Exit.", file=sys.stderr)
         sys.exit(1)
 
-    rows, cols, matrix = read_ps_table(args.psiSPLICEDICE)
+    from . import _stages
+    with _stages.stage("parse"):
+        rows, cols, matrix = read_ps_table(args.psiSPLICEDICE)
     g1_idx = column_indices(g1, cols)
     g2_idx = column_indices(g2, cols)
 
@@ -181,9 +212,10 @@ def run_with(args, ctx=None):
         from . import textio
         # numeric table only: the library's multithreaded formatter (numpy str() of float32 /
         # float64 per column, byte-identical to the reference's print(*fields, sep="\t"))
-        textio.write_columns(args.outputFile, base_header + "\n", [rows[ri] for ri in keep],
-                             [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
-                             ["repr"] * 7)
+        with _stages.stage("format+write"):
+            textio.write_columns(args.outputFile, base_header + "\n", [rows[ri] for ri in keep],
+                                 [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
+                                 ["repr"] * 7)
         return
     from . import textio
     names = [rows[ri] for ri in keep]

@@ -20,7 +20,7 @@ int sd_inclusive_min_scan_u64(sdice_ctx* ctx, int64_t n, const uint64_t* d_in, u
 // bh_cols.hip
 size_t sd_bh_cols_scratch(int64_t m, int64_t segs);
 bool sd_bh_cols_supported(int64_t m, int64_t segs);
-int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_cm, double* d_out, int64_t out_pitch);
+int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm, int64_t pitch);
 bool sd_bh_vector_supported(int64_t n);
 size_t sd_bh_vector_scratch(sdice_ctx* ctx, int64_t n);
 int sd_bh_vector_samplesort(sdice_ctx* ctx, int64_t n, const double* d_p, const uint8_t* d_tested, bool masked, double* d_q);
@@ -312,50 +312,46 @@ extern "C" int sdice_bh(sdice_ctx* ctx, int64_t m, const double* p, double* q) {
     return rc;
 }
 
-// BH down each column of a row-major [n, cols] device table, in place.  Columns are processed in
-// groups so that the scratch (28 bytes per value) stays within `budget` bytes.
-// Columns of up to 2^18 values: sample-sort path (bh_cols.hip).  Column groups are transposed straight out
-// of / back into the row-major table (no dense slab); 30 B of scratch per value.
-static int bh_columns_samplesort(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout) {
+// BH down each column of a row-major [n, cols] device table, in place.
+// Columns of up to 2^18 values: sample-sort path (bh_cols.hip), which reads and writes the row-major table itself;
+// column groups when the scratch (28 B per value) does not fit what is free.
+static int bh_columns_samplesort(sdice_ctx* ctx, int64_t n, int64_t cols, int64_t pitch, double* d_p_inout) {
     size_t free_b = 0, total_b = 0;
     SD_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t arena_b = 0;
     for (auto& c : ctx->arena.chunks) arena_b += c.cap;
     const int64_t budget = (int64_t)((free_b + arena_b) / 10 * 9);
-    int64_t group = std::max<int64_t>(1, (budget - (1 << 20)) / (n * 30 + 49 * 1025));
+    int64_t group = std::max<int64_t>(1, (budget - (1 << 20)) / (n * 28 + 49 * 1025));
     if (group > cols) group = cols;
+    if (group < cols && group > 16) group &= ~(int64_t)15;      // whole 128-byte lines of the row-major table per group
     for (int64_t c0 = 0; c0 < cols; c0 += group) {
         const int64_t gc = std::min(group, cols - c0);
-        int rc = ctx->arena.reserve((size_t)n * (size_t)group * 8 + sd_bh_cols_scratch(n, group), ctx->stream);
+        int rc = ctx->arena.reserve(sd_bh_cols_scratch(n, group), ctx->stream);
         if (rc == SDICE_ERR_NOMEM && group > 1) {            // less memory than hipMemGetInfo promised
             group = (group + 1) / 2;
             c0 -= group;
             continue;
         }
         if (rc != SDICE_OK) return rc;
-        double* d_cm = (double*)ctx->arena.alloc((size_t)n * (size_t)gc * 8);
-        if (!d_cm) return SDICE_ERR_NOMEM;
-        const int64_t chunk = (int64_t)65535 * 32;
-        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-            const int64_t rc_rows = std::min(chunk, n - r0);
-            SD_LAUNCH(ctx, "transpose_f64_kernel", transpose_f64_pitched_kernel,
-                      dim3((unsigned)sd_ceil_div(gc, (int64_t)32), (unsigned)sd_ceil_div(rc_rows, (int64_t)32)), dim3(256), 0,
-                      d_p_inout + r0 * cols + c0, rc_rows, gc, cols, d_cm + r0, n);
-        }
-        SD_TRY(sd_bh_cols_samplesort(ctx, n, gc, d_cm, d_p_inout + c0, cols));
+        SD_TRY(sd_bh_cols_samplesort(ctx, n, gc, d_p_inout + c0, pitch));
     }
     return SDICE_OK;
 }
 
 extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, double* d_p_inout) {
+    return sdice_bh_columns_pitched_dev(ctx, n, cols, cols, d_p_inout);
+}
+
+extern "C" int sdice_bh_columns_pitched_dev(sdice_ctx* ctx, int64_t n, int64_t cols, int64_t pitch, double* d_p_inout) {
     SD_ARG(ctx, "ctx is NULL");
     SD_ARG(n >= 0 && cols >= 0, "negative size");
     if (n == 0 || cols == 0) return SDICE_OK;
     SD_ARG(d_p_inout, "NULL pointer");
+    SD_ARG(pitch >= cols, "pitch must be at least the number of columns");
     SD_HIP(hipSetDevice(ctx->device));
     // bh.columns_path: 0 = by size, 1 = generic radix path, 2 = sample-sort path
     const int64_t path = ctx->param("bh.columns_path", 0);
-    if (path != 1 && sd_bh_cols_supported(n, cols)) return bh_columns_samplesort(ctx, n, cols, d_p_inout);
+    if (path != 1 && sd_bh_cols_supported(n, cols)) return bh_columns_samplesort(ctx, n, cols, pitch, d_p_inout);
     SD_ARG(path != 2, "bh.columns_path = 2 needs columns of at most 2^18 values");
     // columns per group from what is free right now: per value 2 x 8 B (transposed in / out) + 8 B (dense slab
     // when the columns go in groups) + 37 B of sort scratch + histograms; a failed reservation halves the group
@@ -374,7 +370,8 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
         // transposed in/out (+ a dense slab when the columns go in groups), 3 x u64 + 3 x u32 per value
         // for the sort, per-segment histograms (256 x tiles x 4 B) and bin totals
         const size_t vals = (size_t)n * (size_t)group;
-        rc = ctx->arena.reserve(vals * (16 + (group < cols ? 8 : 0) + 37) +
+        const bool slab = group < cols || pitch != cols;     // a column group of the table, or a pitched table: gathered dense first
+        rc = ctx->arena.reserve(vals * (16 + (slab ? 8 : 0) + 37) +
                                     (size_t)group * ((size_t)(n / 3072 + 2) * 1024 + 1024) + (1 << 16), ctx->stream);
         if (rc == SDICE_ERR_NOMEM && group > 1) {            // less memory than hipMemGetInfo promised: fewer columns at once
             group = (group + 1) / 2;
@@ -385,13 +382,13 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
         if (rc != SDICE_OK) break;
         double* d_cm = (double*)ctx->arena.alloc(vals * 8);
         double* d_q = (double*)ctx->arena.alloc(vals * 8);
-        double* d_slab = group < cols ? (double*)ctx->arena.alloc(vals * 8) : nullptr;
-        if (!d_cm || !d_q || (group < cols && !d_slab)) return SDICE_ERR_NOMEM;
+        double* d_slab = slab ? (double*)ctx->arena.alloc(vals * 8) : nullptr;
+        if (!d_cm || !d_q || (slab && !d_slab)) return SDICE_ERR_NOMEM;
         const double* src = d_p_inout;
         int64_t src_cols = cols;
-        if (rc == SDICE_OK && group < cols) {
+        if (rc == SDICE_OK && slab) {
             // gather the column group [c0, c0+gc) into a dense [n, gc] slab first
-            rc = hipMemcpy2DAsync(d_slab, (size_t)gc * 8, d_p_inout + c0, (size_t)cols * 8, (size_t)gc * 8, (size_t)n,
+            rc = hipMemcpy2DAsync(d_slab, (size_t)gc * 8, d_p_inout + c0, (size_t)pitch * 8, (size_t)gc * 8, (size_t)n,
                                   hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? SDICE_OK : SDICE_ERR_HIP;
             src = d_slab;
             src_cols = gc;
@@ -399,10 +396,10 @@ extern "C" int sdice_bh_columns_dev(sdice_ctx* ctx, int64_t n, int64_t cols, dou
         if (rc == SDICE_OK) rc = transpose(ctx, src, n, src_cols, d_cm);
         if (rc == SDICE_OK) rc = bh_segments(ctx, n, gc, d_cm, d_q);
         if (rc == SDICE_OK) {
-            if (group < cols) {
+            if (slab) {
                 rc = transpose(ctx, d_q, gc, n, d_slab);
                 if (rc == SDICE_OK)
-                    rc = hipMemcpy2DAsync(d_p_inout + c0, (size_t)cols * 8, d_slab, (size_t)gc * 8, (size_t)gc * 8, (size_t)n,
+                    rc = hipMemcpy2DAsync(d_p_inout + c0, (size_t)pitch * 8, d_slab, (size_t)gc * 8, (size_t)gc * 8, (size_t)n,
                                           hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? SDICE_OK : SDICE_ERR_HIP;
             } else {
                 rc = transpose(ctx, d_q, gc, n, d_p_inout);

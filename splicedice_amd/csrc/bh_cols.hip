@@ -1,41 +1,49 @@
-// K7 for MANY columns: Benjamini-Hochberg down each of `segs` equally long, contiguous segments of m
-// p-values (the per-pair-column mode of `pairwise`, pairwise_fisher.py:187-191, after the transpose).
+// K7 for MANY columns: Benjamini-Hochberg down each of `segs` columns of m p-values of a row-major table
+// (the per-pair-column mode of `pairwise`, pairwise_fisher.py:187-191), in place.
 //
 // The generic path (bh.hip) sorts (p, index) pairs with eight 8-bit LSD radix passes: ~150 B of HBM
-// traffic per p-value and 58 of the 78 ms that BH took at config 4's per-GPU shard.  BH does not need
-// a stable full sort, though -- only, per value, its rank and the running minimum of p*m/rank from
-// the top rank down.  So here:
-//   1. sample:   per segment, 8 jittered regular samples per bucket, sorted in LDS as (p bits, index)
-//                pairs -- the index breaks ties, so a segment of ONE repeated value (Fisher p-values
-//                are discrete, p = 1 is common) still splits evenly; every 8th is a splitter;
-//   2. count:    tile of 4096 values, binary search over the splitters in LDS, one global atomic
-//                per (tile, bucket);
-//   3. scan:     bucket starts per segment (buckets are contiguous rank ranges);
-//   4. scatter:  same search again, one global atomic per (tile, bucket) reserves a run, 12-byte
-//                (key, index) elements land in their bucket;
-//   5. buckets:  ONE WAVE per bucket (mean ~200 values, up to 1024): bitonic network on registers
-//                (4/8/16 keys per lane, cross-lane steps by ds_bpermute, no LDS storage, no
-//                barriers), ranks = bucket start + position, p*m/rank exactly as the generic path
-//                computes it, suffix minimum inside the bucket, scattered to [segment][index] with
-//                the bucket id beside it; bucket minimum to a small table.  A bucket beyond 1024
-//                values (probability ~1e-10 per bucket) is sorted in place in HBM by its wave;
-//   6. suffix minima of the bucket minima per segment;
-//   7. the transpose back to the row-major table applies min(own, later buckets' minimum, 1).
-// ~70 B of traffic per value and no multi-pass sort; ties need no order (all members of a tie group
-// end with the group's last, smallest p*m/rank), so the result is bit-identical to the generic path.
+// traffic per p-value.  BH does not need a stable full sort, though -- only, per value, its rank and the
+// running minimum of p*m/rank from the top rank down -- and it needs no order inside a tie group (all
+// members of a tie group end with the group's last, smallest p*m/rank).  So here, per column:
+//   1. sample:   8 jittered regular samples per bucket, read straight from the row-major table, sorted in
+//                LDS as (p bits, index) pairs -- the index breaks ties, so a column of ONE repeated value
+//                (Fisher p-values are discrete, p = 1 is common) still splits evenly; every 8th is a splitter;
+//   2. transpose + count: a strip of 16 columns goes row-major -> column-major through LDS (full 128-byte
+//                lines in, 512-byte runs out) and every value is classified on the way (binary search over
+//                its column's splitters in LDS, LDS histogram, one global atomic per (block, column, bucket));
+//   3. scan:     bucket starts per column (buckets are contiguous rank ranges);
+//   4. scatter:  tile of 4096 values of one column, the search again, one global atomic per (tile, bucket)
+//                reserves a run; the 8-byte KEYS land in their bucket, and every value's (bucket, slot) goes to
+//                pos[column][row] -- a coalesced 4-byte store.  No index travels with the keys;
+//   5. buckets:  ONE WAVE per bucket (mean ~200 values): key-only bitonic network on registers (DPP and lane
+//                swaps, no LDS crossbar), ranks = bucket start + position, p*m/rank exactly as the generic path
+//                computes it, suffix minimum inside the bucket; sorted keys and minima parked in the wave's LDS,
+//                every value finds its rank by binary search there and its result is written back IN PLACE,
+//                to the slot its key came from (a coalesced 8-byte store); bucket minimum to a small table;
+//   6. suffix minima of the bucket minima per column;
+//   7. finish:   the transpose back to the row-major table GATHERS: value (row, column) reads pos, takes its
+//                result from the slot, applies min(own, later buckets' minimum, 1).
+// Nothing is scattered at 8-byte granularity (rounds 1-3 scattered the results to [column][row] from the bucket
+// kernel: 27 GB written for 4 GB of results at 25 000 x 19 900); the one random access left is step 7's 8-byte
+// read inside a column's 200 KB of results, which the block -> XCD mapping keeps in one L2.  ~36 B of
+// algorithmic traffic per value; bit-identical to the generic path.
 #include "common.h"
 #include <algorithm>
 #include <stdio.h>
 
 namespace {
 
-constexpr int TILE_T = 512;         // threads of a count / scatter tile
+constexpr int TILE_T = 512;         // threads of a scatter tile
 constexpr int TILE_E = 8;           // values per thread
 constexpr int TILE = TILE_T * TILE_E;
 constexpr int MAX_B = 1024;
+constexpr int POS_SHIFT = 18;       // pos word: bucket << 18 | slot inside the column (m <= 2^18, buckets <= 2^10)
+constexpr unsigned POS_MASK = (1u << POS_SHIFT) - 1u;
 
 struct BhsArgs {
-    const double* p_cm;     // [segs][m]
+    const double* p_rm;     // row-major input: value (r, c) at p_rm[r * pitch + c]
+    int64_t pitch;
+    double* p_cm;           // [segs][m] transposed input
     int64_t m;
     int segs;
     int B;                  // buckets per segment
@@ -46,17 +54,16 @@ struct BhsArgs {
     unsigned* gcount;       // [segs][B]
     unsigned* start;        // [segs][B+1]
     unsigned* cursor;       // [segs][B]
-    uint64_t* keyS;         // [segs][m] bucketed keys
-    uint32_t* idxS;
-    uint64_t* q_cm;         // [segs][m] p*m/rank, suffix minimum inside the bucket (f64 bits)
-    uint16_t* bid_cm;       // [segs][m] bucket of each value
+    uint64_t* keyS;         // [segs][m] bucketed keys; the bucket kernel overwrites every key with its result
+    uint32_t* pos_cm;       // [segs][m] bucket << 18 | slot of each value (NULL: one bucket, slot = row)
     uint64_t* bmin;         // [segs][B]
     uint64_t* sfx;          // [segs][B] minimum over the LATER buckets
-    unsigned* big_count;    // [8] buckets of more than 256 values: work lists of the second bucket kernel, one per XCD
-    int64_t* big_list;      // [8][big_region]: list x holds buckets of the segments with seg mod 8 == x
-    int64_t big_region;
-    int reg_cap;            // buckets beyond this many values take the in-HBM path (1024; lower in tests)
-    int ablate;             // timing experiments (param bh.ablate; results are wrong when set): 1 no q store, 2 no bucket-id store
+    unsigned* big_count;    // buckets beyond the main kernel's network: work list of the second bucket kernel
+    int64_t* big_list;
+    uint64_t* spill;        // [segs * m] scratch of the in-HBM bucket path (adversarial input only), bump-allocated
+    unsigned long long* spill_n;
+    int reg_cap;            // buckets beyond this many values take the in-HBM path (2048; lower in tests)
+    int ablate;             // timing experiments (param bh.ablate; results are wrong when set)
 };
 
 __device__ __forceinline__ uint64_t key_of(double v) {
@@ -95,21 +102,20 @@ __device__ __forceinline__ int find_bucket(const uint64_t* sk, const uint32_t* s
     }
     return lo;
 }
-
 // ---------------------------------------------------------------- 1. splitters
 __global__ void __launch_bounds__(256) bhs_sample_kernel(BhsArgs a) {
     extern __shared__ uint64_t smem_s[];
     uint64_t* sk = smem_s;
     uint32_t* si = reinterpret_cast<uint32_t*>(sk + a.S2);
     const int seg = blockIdx.x, tid = threadIdx.x;
-    const double* p = a.p_cm + (int64_t)seg * a.m;
+    const double* p = a.p_rm + seg;                      // column `seg` of the row-major table
     for (int j = tid; j < a.S2; j += 256) {
         uint64_t k = ~0ull;
         uint32_t i = ~0u;
         if (j < a.S) {
             const int64_t lo = (int64_t)j * a.m / a.S, hi = (int64_t)(j + 1) * a.m / a.S;
             const int64_t pos = lo + (int64_t)(hash32((unsigned)seg * 40503u + (unsigned)j) % (unsigned)(hi - lo));
-            k = key_of(p[pos]);
+            k = key_of(p[pos * a.pitch]);
             i = (uint32_t)pos;
         }
         sk[j] = k;
@@ -136,7 +142,67 @@ __global__ void __launch_bounds__(256) bhs_sample_kernel(BhsArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- 2. / 4. count and scatter
+// ---------------------------------------------------------------- 2. transpose in (+ count)
+// A workgroup owns a strip of TC_COLS columns x rows_per_block rows: row segments of 128 bytes in, runs of TC_ROWS
+// doubles per column out.  COUNT: every value is classified against its column's splitters (LDS) on the way; the
+// histogram stays in LDS until the workgroup is through its rows.
+constexpr int TC_COLS = 16, TC_ROWS = 128, TC_T = 256;
+template <bool COUNT>
+__global__ void __launch_bounds__(TC_T) bhs_transpose_kernel(BhsArgs a, int rows_per_block) {
+    extern __shared__ uint64_t smem_tc[];
+    __shared__ double tile[TC_COLS][TC_ROWS + 1];
+    const int ns = a.B - 1;
+    uint64_t* sk = smem_tc;                                               // [TC_COLS][ns]
+    uint32_t* si = reinterpret_cast<uint32_t*>(sk + (COUNT ? TC_COLS * ns : 0));    // [TC_COLS][ns]
+    unsigned* hist = reinterpret_cast<unsigned*>(si + (COUNT ? TC_COLS * ns : 0));  // [TC_COLS][B]
+
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * TC_COLS;
+    const int ncol = (int)min((int64_t)TC_COLS, (int64_t)a.segs - c0);
+    const int64_t rb0 = (int64_t)blockIdx.y * rows_per_block, rb1 = min(a.m, rb0 + rows_per_block);
+    if (COUNT) {
+        for (int i = tid; i < ncol * ns; i += TC_T) {
+            const int c = i / ns, b = i - c * ns;
+            sk[c * ns + b] = a.spl_k[(c0 + c) * a.B + b];
+            si[c * ns + b] = a.spl_i[(c0 + c) * a.B + b];
+        }
+        for (int i = tid; i < TC_COLS * a.B; i += TC_T) hist[i] = 0u;
+        __syncthreads();
+    }
+    const int col = tid & (TC_COLS - 1), rsub = tid >> 4;                 // 16 rows x 16 columns per pass
+    constexpr int PASSES = TC_ROWS / (TC_T / TC_COLS);                    // 8
+    for (int64_t r0 = rb0; r0 < rb1; r0 += TC_ROWS) {
+        double v[PASSES];
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int64_t row = r0 + rsub + 16 * j;
+            v[j] = (row < rb1 && col < ncol) ? __builtin_nontemporal_load(a.p_rm + row * a.pitch + c0 + col) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int64_t row = r0 + rsub + 16 * j;
+            tile[col][rsub + 16 * j] = v[j];
+            if (COUNT && row < rb1 && col < ncol) {
+                const int bkt = find_bucket(sk + col * ns, si + col * ns, ns, key_of(v[j]), (uint32_t)row);
+                atomicAdd(&hist[col * a.B + bkt], 1u);
+            }
+        }
+        __syncthreads();
+        const int nrow = (int)min((int64_t)TC_ROWS, rb1 - r0);
+        for (int i = tid; i < TC_COLS * TC_ROWS; i += TC_T) {
+            const int c = i / TC_ROWS, rr = i - c * TC_ROWS;
+            if (c < ncol && rr < nrow) a.p_cm[(c0 + c) * a.m + r0 + rr] = tile[c][rr];
+        }
+        __syncthreads();
+    }
+    if (COUNT) {
+        for (int i = tid; i < ncol * a.B; i += TC_T)
+            if (hist[i]) atomicAdd(&a.gcount[c0 * a.B + i], hist[i]);         // (hist is [column][B], as gcount)
+    }
+}
+
+// ---------------------------------------------------------------- 2b. / 4. count (many buckets: the splitters of a
+// strip do not fit LDS beside the transpose) and scatter
 template <bool SCATTER>
 __global__ void __launch_bounds__(TILE_T) bhs_tile_kernel(BhsArgs a, int tiles) {
     extern __shared__ uint64_t smem_t[];
@@ -164,7 +230,7 @@ __global__ void __launch_bounds__(TILE_T) bhs_tile_kernel(BhsArgs a, int tiles) 
 #pragma unroll
     for (int q = 0; q < TILE_E; ++q) {
         const int64_t e = e0 + q * TILE_T + tid;
-        key[q] = e < a.m ? key_of(p[e]) : 0;
+        key[q] = e < a.m ? key_of(__builtin_nontemporal_load(p + e)) : 0;
     }
 #pragma unroll
     for (int q = 0; q < TILE_E; ++q) {
@@ -187,9 +253,9 @@ __global__ void __launch_bounds__(TILE_T) bhs_tile_kernel(BhsArgs a, int tiles) 
 #pragma unroll
     for (int q = 0; q < TILE_E; ++q) {
         if (bkt[q] >= 0) {
-            const int64_t dst = (int64_t)seg * a.m + base[bkt[q]] + off[q];
-            a.keyS[dst] = key[q];
-            a.idxS[dst] = (uint32_t)(e0 + q * TILE_T + tid);
+            const unsigned slot = base[bkt[q]] + off[q];
+            a.keyS[(int64_t)seg * a.m + slot] = key[q];
+            a.pos_cm[(int64_t)seg * a.m + e0 + q * TILE_T + tid] = ((unsigned)bkt[q] << POS_SHIFT) | slot;      // (coalesced)
         }
     }
 }
@@ -239,48 +305,8 @@ __device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int d) {
     const unsigned hi = (unsigned)__shfl_down((int)(unsigned)(v >> 32), d);
     return ((uint64_t)hi << 32) | lo;
 }
-
-// ascending bitonic network over 64*K (key, val) pairs; pair at position lane*K + k
-template <int K>
-__device__ __forceinline__ void wave_bitonic(uint64_t (&key)[K], uint32_t (&val)[K], const int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64 * K; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j >= 1; j >>= 1) {
-            if (j >= K) {
-                const int lm = j / K;
-                const bool lower = (lane & lm) == 0;
-                const bool up = k2 >= 64 * K ? true : (lane & (k2 / K)) == 0;
-                const bool keep_min = lower == up;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint64_t o = shfl_xor_u64(key[k], lm);
-                    const uint32_t ov = (uint32_t)__shfl_xor((int)val[k], lm);
-                    const bool take = keep_min ? o < key[k] : o > key[k];
-                    key[k] = take ? o : key[k];
-                    val[k] = take ? ov : val[k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int kp = k ^ j;
-                    if (kp > k) {
-                        bool up;
-                        if (k2 < K) up = (k & k2) == 0;
-                        else if (k2 >= 64 * K) up = true;
-                        else up = (lane & (k2 / K)) == 0;
-                        const bool sw = up ? key[kp] < key[k] : key[kp] > key[k];
-                        const uint64_t tk = key[k];
-                        const uint32_t tv = val[k];
-                        key[k] = sw ? key[kp] : tk;
-                        val[k] = sw ? val[kp] : tv;
-                        key[kp] = sw ? tk : key[kp];
-                        val[kp] = sw ? tv : val[kp];
-                    }
-                }
-            }
-        }
-    }
+__device__ __forceinline__ uint64_t bcast_lane0_u64(uint64_t v) {
+    return ((uint64_t)(unsigned)__shfl((int)(unsigned)(v >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)(v & 0xffffffffu), 0);
 }
 
 __device__ __forceinline__ uint64_t raw_bits(uint64_t key, int64_t rank1, int64_t m) {
@@ -289,240 +315,97 @@ __device__ __forceinline__ uint64_t raw_bits(uint64_t key, int64_t rank1, int64_
     const double ecdf = (double)rank1 / (double)m;
     return (uint64_t)__double_as_longlong(ps / ecdf);
 }
-
-template <int K>
-__device__ __forceinline__ void bucket_in_regs(const BhsArgs& a, const uint64_t* ks, const uint32_t* is, const double* pd,
-                                               int n_b, int64_t seg_off, unsigned start, int bucket, int lane,
-                                               uint64_t* bmin_out) {
-    uint64_t key[K];
-    uint32_t val[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int p = k * 64 + lane;              // coalesced; the starting arrangement is arbitrary anyway
-        key[k] = ~0ull;
-        val[k] = 0u;
-        if (p < n_b) {
-            if (pd) { key[k] = key_of(pd[p]); val[k] = (uint32_t)p; }
-            else { key[k] = ks[p]; val[k] = is[p]; }
-        }
-    }
-    wave_bitonic<K>(key, val, lane);
-    uint64_t s[K];
-    uint64_t run = ~0ull;
-#pragma unroll
-    for (int k = K - 1; k >= 0; --k) {
-        const int p = lane * K + k;
-        const uint64_t r = p < n_b ? raw_bits(key[k], (int64_t)start + p + 1, a.m) : ~0ull;
-        run = r < run ? r : run;
-        s[k] = run;
-    }
-    uint64_t x = run;                              // inclusive suffix minimum over the lanes >= this one
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t y = shfl_down_u64(x, o);
-        if (lane + o < 64) x = y < x ? y : x;
-    }
-    uint64_t ex = shfl_down_u64(x, 1);
-    if (lane == 63) ex = ~0ull;
-    if (lane == 0) *bmin_out = x;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int p = lane * K + k;
-        if (p < n_b) {
-            const uint64_t v = s[k] < ex ? s[k] : ex;
-            a.q_cm[seg_off + val[k]] = v;
-            a.bid_cm[seg_off + val[k]] = (uint16_t)bucket;
-        }
-    }
+// the same value with the first division by arithmetic: rank1 and m are integers below 2^53 with rank1 <= m <= 2^18, so
+// the quotient lies at least 2^-18 ulp off every rounding boundary, and q0 = rank1 * (1 / m) corrected by its exact
+// residual is the correctly rounded quotient (exhaustive over all ranks of 3000 random and 21 chosen column lengths:
+// tests/test_abi_and_host.py::test_rank_over_m_by_reciprocal); inv_m = 1.0 / m by the IEEE division, once per wave
+__device__ __forceinline__ uint64_t raw_bits_inv(uint64_t key, int rank1, double m, double inv_m) {
+    const double ps = __longlong_as_double((long long)key);
+    const double a = (double)rank1;
+    const double q0 = a * inv_m;
+    const double ecdf = __builtin_fma(__builtin_fma(-q0, m, a), inv_m, q0);
+    return (uint64_t)__double_as_longlong(ps / ecdf);
 }
 
-// ---- key-only network (the default bucket path) --------------------------------------------------------------
-// BH needs no order inside a tie group (all its members end with the group's last, smallest p * m / rank), so the
-// network moves KEYS ONLY -- half the registers and half the exchange traffic of (key, index) pairs -- and every value
-// then finds its rank by a binary search over the sorted keys, which the wave parks in LDS together with the suffix
-// minima (lower bound: the first member of its tie group; the suffix minimum from there is the group's value).
-// Lane exchanges by DPP (xor 1, 2, 4, 8: VALU rate, no LDS crossbar) and the gfx950 lane swaps (xor 16, 32); a swap
-// hands over BOTH operands of the compare-exchange, which is symmetric in them.
-template <int M> __device__ __forceinline__ unsigned dpp_xor(unsigned x) {
-    if (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
-    if (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
-    if (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);         // row_ror:8
-    // xor 4: banks 1, 3 take lane - 4 (row_ror:4), banks 0, 2 take lane + 4 (row_ror:12)
-    const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xF, 0xA, false);
-    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x12C, 0xF, 0x5, false);
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t y = shfl_xor_u64(v, o); v = y < v ? y : v; }
+    return v;
 }
-// compare-exchange of `key` with lane ^ M: the lane keeps the smaller key iff keep_min
-template <int M> __device__ __forceinline__ uint64_t cx_lane(uint64_t key, bool keep_min) {
-    uint64_t a, b;
-    if (M >= 16) {
-        const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
-        if (M == 32) {
-            const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-            const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-            a = ((uint64_t)rh[0] << 32) | rl[0]; b = ((uint64_t)rh[1] << 32) | rl[1];
-        } else {
-            const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-            const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-            a = ((uint64_t)rh[0] << 32) | rl[0]; b = ((uint64_t)rh[1] << 32) | rl[1];
-        }
-    } else {
-        a = key;
-        b = ((uint64_t)dpp_xor<M>((unsigned)(key >> 32)) << 32) | dpp_xor<M>((unsigned)key);
-    }
-    return ((a < b) == keep_min) ? a : b;
-}
-// ascending bitonic network over 64 * K keys; key at position lane * K + k
-template <int K>
-__device__ __forceinline__ void wave_bitonic_keys(uint64_t (&key)[K], const int lane) {
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
-    for (int k2 = 2; k2 <= 64 * K; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j >= 1; j >>= 1) {
-            if (j >= K) {
-                const int lm = j / K;
-                const bool lower = (lane & lm) == 0;
-                const bool up = k2 >= 64 * K ? true : (lane & (k2 / K)) == 0;
-                const bool keep_min = lower == up;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    if (lm == 1) key[k] = cx_lane<1>(key[k], keep_min);
-                    else if (lm == 2) key[k] = cx_lane<2>(key[k], keep_min);
-                    else if (lm == 4) key[k] = cx_lane<4>(key[k], keep_min);
-                    else if (lm == 8) key[k] = cx_lane<8>(key[k], keep_min);
-                    else if (lm == 16) key[k] = cx_lane<16>(key[k], keep_min);
-                    else key[k] = cx_lane<32>(key[k], keep_min);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int kp = k ^ j;
-                    if (kp > k) {
-                        bool up;
-                        if (k2 < K) up = (k & k2) == 0;
-                        else if (k2 >= 64 * K) up = true;
-                        else up = (lane & (k2 / K)) == 0;
-                        const uint64_t x = key[k], y = key[kp];
-                        const bool sw = (y < x) == up;
-                        key[k] = sw ? y : x;
-                        key[kp] = sw ? x : y;
-                    }
-                }
-            }
-        }
-    }
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t y = shfl_xor_u64(v, o); v = y > v ? y : v; }
+    return v;
 }
 
-// one bucket of up to 64 * K values by one wave; SK / SQ: this wave's 64 * K words of LDS each
-template <int K>
-__device__ __forceinline__ void bucket_keys_only(const BhsArgs& a, const uint64_t* ks, const uint32_t* is, const double* pd,
-                                                 int n_b, int64_t seg_off, unsigned start, int bucket, int lane,
-                                                 uint64_t* bmin_out, uint64_t* SK, uint64_t* SQ) {
-    uint64_t key[K], sk[K];
-    uint32_t val[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int p = k * 64 + lane;              // coalesced; the starting arrangement is arbitrary anyway
-        key[k] = ~0ull;
-        val[k] = 0u;
-        if (p < n_b) {
-            if (pd) { key[k] = key_of(pd[p]); val[k] = (uint32_t)p; }
-            else { key[k] = __builtin_nontemporal_load(ks + p); val[k] = __builtin_nontemporal_load(is + p); }
-        }
-        sk[k] = key[k];
-    }
-    wave_bitonic_keys<K>(sk, lane);
-    uint64_t s[K];
-    uint64_t run = ~0ull;
-#pragma unroll
-    for (int k = K - 1; k >= 0; --k) {
-        const int p = lane * K + k;
-        const uint64_t r = p < n_b ? raw_bits(sk[k], (int64_t)start + p + 1, a.m) : ~0ull;
-        run = r < run ? r : run;
-        s[k] = run;
-    }
-    uint64_t x = run;                              // inclusive suffix minimum over the lanes >= this one
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t y = shfl_down_u64(x, o);
-        if (lane + o < 64) x = y < x ? y : x;
-    }
-    uint64_t ex = shfl_down_u64(x, 1);
-    if (lane == 63) ex = ~0ull;
-    if (lane == 0) *bmin_out = x;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        SK[lane * K + k] = sk[k];
-        SQ[lane * K + k] = s[k] < ex ? s[k] : ex;
-    }
-    // (LDS operations of one wave execute in order: the reads below see the writes above)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // lower bound of each own key among the sorted keys: branch-free, K independent chains
-    int pos[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) pos[k] = 0;
-#pragma unroll
-    for (int st = 32 * K; st >= 1; st >>= 1) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) pos[k] += SK[pos[k] + st - 1] < key[k] ? st : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (k * 64 + lane < n_b) {
-            if (!(a.ablate & 1)) a.q_cm[seg_off + val[k]] = SQ[pos[k]];
-            if (!(a.ablate & 2)) a.bid_cm[seg_off + val[k]] = (uint16_t)bucket;
-            if (a.ablate & 4) a.q_cm[seg_off + start + k * 64 + lane] = SQ[pos[k]];      // (coalesced instead)
-        }
-    }
-}
+// ---- ranking a bucket by a COUNTING SORT in LDS instead of a comparison network.  The bucket's keys lie between two
+// splitters, so (key - lo) >> sh -- sh the shift that brings the bucket's key range below the number of bins; integer
+// arithmetic on the bit patterns: monotone for ANY input, linear in the value inside a binade -- spreads them over the
+// bins at less than one key per bin.  An LDS atomic per value counts its bin and hands it a slot in it, a scan over the
+// bins gives their starts, the keys go to their bin's list, and every value counts the members of its OWN bin that
+// come before it in (key, slot) order: rank = bin start + that count (a bin of ONE repeated value -- Fisher's p = 1
+// fills whole buckets -- is recognised and ranked by slot alone).  A bin of many DIFFERENT values (values a few ulps
+// apart in a wide bucket) degrades to the quadratic count, at worst about the cost of a sorting network.  Then
+// p * m / rank as the generic path computes it, results to L[rank], suffix minima over the ranks in place, and every
+// value reads its own back: members of a tie group hold distinct ranks in arbitrary order, and since p * m / rank falls
+// inside a group, the suffix minimum from any of them is the group's last, i.e. the group's value.
+// (Rounds 1-3 sorted (key, index) pairs per bucket with a bitonic network on registers, one wave per bucket; a
+// key-only network with DPP / lane-swap exchanges and a wave-per-bucket form of this counting sort were measured on the
+// way: DESIGN.md appendix A.4.)
 
-// rare: more than 1024 values in one bucket -- its wave sorts it in place in HBM (all-ascending
-// bitonic network: out-of-range partners count as +inf and never move), then walks it from the end
-__device__ void bucket_in_hbm(const BhsArgs& a, uint64_t* ks, uint32_t* is, int n_b, int64_t seg_off, unsigned start,
-                              int bucket, int lane, uint64_t* bmin_out) {
+// rare (adversarial input): more values in one bucket than the widest network holds -- its wave sorts a copy in HBM
+// (all-ascending bitonic network: out-of-range partners count as +inf and never move), ranks the bucket's values by
+// binary search in the copy, turns the copy into suffix minima and puts every value's result into its slot
+__device__ void bucket_in_hbm(const BhsArgs& a, uint64_t* ks, int n_b, unsigned start, int lane, uint64_t* bmin_out) {
+    unsigned long long so = 0;
+    if (lane == 0) so = atomicAdd(a.spill_n, (unsigned long long)n_b);
+    uint64_t* t = a.spill + bcast_lane0_u64(so);
+    for (int p = lane; p < n_b; p += 64) t[p] = ks[p];
+    __threadfence_block();
     int P = 1;
     while (P < n_b) P <<= 1;
     for (int k2 = 2; k2 <= P; k2 <<= 1) {
         for (int j = k2 >> 1; j >= 1; j >>= 1) {
-            for (int t = lane; t < (P >> 1); t += 64) {
+            for (int q = lane; q < (P >> 1); q += 64) {
                 int i, l;
                 if (j == (k2 >> 1)) {              // first step of a merge: mirror partner
-                    const int blk = t / j, r = t - blk * j;
+                    const int blk = q / j, r = q - blk * j;
                     i = blk * k2 + r;
                     l = blk * k2 + k2 - 1 - r;
                 } else {
-                    i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                     l = i | j;
                 }
                 if (l < n_b) {
-                    const uint64_t ka = ks[i], kb = ks[l];
-                    if (kb < ka) {
-                        const uint32_t ia = is[i], ib = is[l];
-                        ks[i] = kb; ks[l] = ka; is[i] = ib; is[l] = ia;
-                    }
+                    const uint64_t ka = t[i], kb = t[l];
+                    if (kb < ka) { t[i] = kb; t[l] = ka; }
                 }
             }
             __threadfence_block();
         }
     }
+    for (int p = lane; p < n_b; p += 64) {         // rank of value p: lower bound in the sorted copy
+        const uint64_t k = ks[p];
+        int lo = 0, hi = n_b;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (t[mid] < k) lo = mid + 1; else hi = mid; }
+        ks[p] = (uint64_t)lo;
+    }
+    __threadfence_block();
     uint64_t carry = ~0ull;
     for (int c = (n_b - 1) / 64; c >= 0; --c) {
         const int p = c * 64 + lane;
-        uint64_t x = p < n_b ? raw_bits(ks[p], (int64_t)start + p + 1, a.m) : ~0ull;
+        uint64_t x = p < n_b ? raw_bits(t[p], (int64_t)start + p + 1, a.m) : ~0ull;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint64_t y = shfl_down_u64(x, o);
             if (lane + o < 64) x = y < x ? y : x;
         }
         x = carry < x ? carry : x;
-        if (p < n_b) {
-            a.q_cm[seg_off + is[p]] = x;
-            a.bid_cm[seg_off + is[p]] = (uint16_t)bucket;
-        }
-        carry = ((uint64_t)(unsigned)__shfl((int)(unsigned)(x >> 32), 0) << 32) |
-                (unsigned)__shfl((int)(unsigned)(x & 0xffffffffu), 0);     // lane 0's value for everyone
+        if (p < n_b) t[p] = x;
+        carry = bcast_lane0_u64(x);
     }
+    __threadfence_block();
+    for (int p = lane; p < n_b; p += 64) ks[p] = t[ks[p]];
     if (lane == 0) *bmin_out = carry;
 }
 
@@ -530,76 +413,219 @@ __device__ void bucket_in_hbm(const BhsArgs& a, uint64_t* ks, uint32_t* is, int 
 struct BucketRef {
     int seg, b, n_b;
     unsigned start;
-    int64_t seg_off;
     const double* pd;
     uint64_t* ks;
-    uint32_t* is;
     uint64_t* bm;
+    uint64_t lo, hi;        // bounds of the bucket's keys (the splitters on either side)
+    bool end;               // first / last bucket of a column, or the column's only one: bounds from the keys
 };
 __device__ __forceinline__ BucketRef bucket_ref(const BhsArgs& a, int64_t g) {
     BucketRef r;
     r.seg = (int)(g / a.B);
     r.b = (int)(g - (int64_t)r.seg * a.B);
-    r.seg_off = (int64_t)r.seg * a.m;
+    const int64_t seg_off = (int64_t)r.seg * a.m;
     r.start = 0;
     r.n_b = (int)a.m;
-    r.pd = nullptr; r.ks = nullptr; r.is = nullptr;
+    r.pd = nullptr;
+    r.ks = a.keyS + seg_off;
+    r.lo = 0; r.hi = 0;
+    r.end = r.b == 0 || r.b == a.B - 1;
     if (a.B == 1) {
-        r.pd = a.p_cm + r.seg_off;                 // short segments: no partition, straight from the p-values
+        r.pd = a.p_cm + seg_off;                   // short columns: no partition, straight from the p-values
     } else {
         r.start = a.start[(int64_t)r.seg * (a.B + 1) + r.b];
         r.n_b = (int)(a.start[(int64_t)r.seg * (a.B + 1) + r.b + 1] - r.start);
-        r.ks = a.keyS + r.seg_off + r.start;
-        r.is = a.idxS + r.seg_off + r.start;
+        r.ks += r.start;
+        if (!r.end) { r.lo = a.spl_k[(int64_t)r.seg * a.B + r.b - 1]; r.hi = a.spl_k[(int64_t)r.seg * a.B + r.b]; }
     }
     r.bm = a.bmin + (int64_t)r.seg * a.B + r.b;
     return r;
 }
 
-// buckets of up to 256 values (nearly all of them): 4 keys per lane, ~40 VGPRs, 8 waves per SIMD.
-// Larger buckets go to a work list for bhs_bucket_big_kernel (whose 16-keys-per-lane network needs
-// 150 VGPRs: in one kernel it held every wave to 3 per SIMD and the loads' latency was not hidden).
-// Workgroups are dealt round-robin over the 8 XCDs and each XCD has its own L2: all buckets of one segment
-// go to workgroups of ONE XCD (segment mod 8), so that the scattered 8-byte results of a segment -- every
-// cache line of its 200 KB gets its 16 values from 16 different buckets -- meet in one L2 and leave it as
-// full lines.  (With buckets dealt over all XCDs every L2 wrote its own partial lines: 26.7 GB of write
-// traffic for 5 GB of results.)
-template <int K>
-__global__ void __launch_bounds__(256) bhs_bucket_kernel(BhsArgs a, int blocks_per_seg) {
-    __shared__ uint64_t SK[4][64 * K], SQ[4][64 * K];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: the bucket's addresses stay in SGPRs)
-    const int64_t k = (int64_t)(blockIdx.x >> 3);
-    const int64_t seg_x = (k / blocks_per_seg) * 8 + (blockIdx.x & 7);
-    const int b_x = (int)(k % blocks_per_seg) * 4 + wave;
-    if (seg_x >= a.segs || b_x >= a.B) return;
-    const int64_t g = seg_x * a.B + b_x;
-    const BucketRef r = bucket_ref(a, g);
-    if (r.n_b <= 64 * K && r.n_b <= a.reg_cap) {
-        bucket_keys_only<K>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm, SK[wave], SQ[wave]);
-    } else if (lane == 0) {
-        // (one list per XCD: the big kernel's workgroups keep to the list of "their" segments, so that the scattered
-        //  results of a segment still meet in ONE L2 -- a single list in arrival order spread them over all eight)
-        const int x = (int)(seg_x & 7);
-        const unsigned slot = atomicAdd(&a.big_count[x], 1u);
-        a.big_list[(int64_t)x * a.big_region + slot] = g;
+// ---- one WORKGROUP per bucket: T threads, K values per thread, NS = T K slots, 2 NS bins.  Large buckets mean few of
+// them per column -- long runs in the scatter, few search steps everywhere, a small sample to sort -- and a workgroup
+// ranks a large bucket at K = 4 values per thread (48 VGPRs) where one wave per bucket would need 16 and more per lane.
+// Workgroup barriers between the phases; the resolving loop's trip count stays per WAVE (the largest mixed bin among ITS
+// values).  LDS: L[NS] (8 B) | CNT[2 NS + 4] (4 B) | wred[32] (8 B) | wtot[16] (4 B) = 16 NS + 336 bytes.
+template <int T, int K>
+__device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef& r, uint64_t* smem) {
+    constexpr int NS = T * K, BINS = 2 * NS, NW = T / 64;
+    constexpr int LOGB = NS == 1024 ? 11 : NS == 2048 ? 12 : 13;
+    static_assert(NS == 1024 || NS == 2048 || NS == 4096, "slots");
+    uint64_t* L = smem;                                               // [NS]
+    uint64_t* wred = L + NS;                                          // [2 NW]
+    unsigned* CNT = reinterpret_cast<unsigned*>(wred + 32);          // [BINS + 4]
+    unsigned* wtot = CNT + BINS + 4;                                  // [NW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_b = r.n_b;
+    uint64_t key[K];
+    bool ok[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int p = k * T + tid;                // coalesced
+        ok[k] = p < n_b;
+        key[k] = 0;
+        if (ok[k]) key[k] = r.pd ? key_of(r.pd[p]) : __builtin_nontemporal_load(r.ks + p);
     }
+    for (int i = tid; i < BINS + 1; i += T) CNT[i] = 0u;
+    uint64_t lo = r.lo, hi = r.hi;
+    if (r.end) {                                   // (block-uniform) bounds from the keys
+        uint64_t mn = ~0ull, mx = 0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { if (ok[k]) { mn = key[k] < mn ? key[k] : mn; mx = key[k] > mx ? key[k] : mx; } }
+        mn = wave_min_u64(mn);
+        mx = wave_max_u64(mx);
+        if (lane == 0) { wred[wave] = mn; wred[NW + wave] = mx; }
+        __syncthreads();
+        lo = wred[0]; hi = wred[NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { lo = wred[w] < lo ? wred[w] : lo; hi = wred[NW + w] > hi ? wred[NW + w] : hi; }
+    }
+    const uint64_t range = hi - lo;
+    const int bits = range ? 64 - __builtin_clzll(range) : 0;
+    const int sh = __builtin_amdgcn_readfirstlane(bits > LOGB ? bits - LOGB : 0);
+    __syncthreads();
+    int bin[K];
+    unsigned slot[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint64_t d = (key[k] - lo) >> sh;
+        bin[k] = (int)(d < (uint64_t)(BINS - 1) ? d : (uint64_t)(BINS - 1));
+        slot[k] = 0u;
+        if (ok[k]) slot[k] = atomicAdd(&CNT[bin[k]], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan over the bins: thread t owns bins [2 K t, 2 K t + 2 K)
+        unsigned c[2 * K], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 2 * K; ++j) { c[j] = CNT[tid * 2 * K + j]; tot += c[j]; }
+        unsigned x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        unsigned pre = x - tot;
+        for (int w = 0; w < wave; ++w) pre += wtot[w];
+#pragma unroll
+        for (int j = 0; j < 2 * K; ++j) { CNT[tid * 2 * K + j] = pre; pre += c[j]; }
+        if (tid == T - 1) CNT[BINS] = pre;
+    }
+    __syncthreads();
+    int sb[K], cb[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        sb[k] = (int)CNT[bin[k]];
+        cb[k] = ok[k] ? (int)CNT[bin[k] + 1] - sb[k] : 0;
+        if (!ok[k]) sb[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (ok[k]) L[sb[k] + (int)slot[k]] = key[k];
+    __syncthreads();
+    // a bin of ONE repeated value needs no order (rank = start + slot); a value that differs from its bin's first member
+    // marks the bin (top bit of its start word) and only marked bins are resolved by counting
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (ok[k] && L[sb[k]] != key[k]) atomicOr(&CNT[bin[k]], 0x80000000u);
+    __syncthreads();
+    unsigned before[K];
+    int cmax = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool mixed = ok[k] && (CNT[bin[k]] & 0x80000000u) != 0u;
+        before[k] = mixed ? 0u : slot[k];
+        if (!mixed) cb[k] = 0;
+        cmax = cb[k] > cmax ? cb[k] : cmax;
+    }
+    for (int i = 0; __ballot(i < cmax) != 0ull; ++i) {
+        uint64_t kj[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) kj[k] = L[sb[k] + (i < cb[k] ? i : 0)];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool in = i < cb[k];
+            count_less96(before[k], in ? kj[k] : ~0ull, in ? (unsigned)i : ~0u, key[k], slot[k]);
+        }
+    }
+    int rank[K];
+    uint64_t raw[K];
+    const double md = (double)a.m, inv_m = 1.0 / md;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        rank[k] = sb[k] + (int)before[k];
+        raw[k] = raw_bits_inv(key[k], (int)r.start + rank[k] + 1, md, inv_m);
+    }
+    __syncthreads();                               // every read of the lists is done: L becomes the rank-ordered array
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (ok[k]) L[rank[k]] = raw[k];
+    __syncthreads();
+    {   // suffix minima over the ranks in place: thread t owns ranks [t K, t K + K)
+        uint64_t sfx[K];
+        uint64_t run = ~0ull;
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) {
+            const int p = tid * K + j;
+            const uint64_t v = p < n_b ? L[p] : ~0ull;
+            run = v < run ? v : run;
+            sfx[j] = run;
+        }
+        uint64_t x = run;                          // inclusive suffix minimum over the lanes >= this one
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = shfl_down_u64(x, o);
+            if (lane + o < 64) x = y < x ? y : x;
+        }
+        uint64_t ex = shfl_down_u64(x, 1);
+        if (lane == 63) ex = ~0ull;
+        if (lane == 0) wred[wave] = x;
+        __syncthreads();
+        for (int w = wave + 1; w < NW; ++w) ex = wred[w] < ex ? wred[w] : ex;     // (minima of the waves behind this one)
+        if (tid == 0) {
+            uint64_t all = wred[0];
+            for (int w = 1; w < NW; ++w) all = wred[w] < all ? wred[w] : all;
+            *r.bm = all;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (tid * K + j < n_b) L[tid * K + j] = sfx[j] < ex ? sfx[j] : ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (ok[k]) r.ks[k * T + tid] = L[rank[k]];        // in place: the slot the key came from
+}
+template <int T, int K> constexpr size_t bucket_wg_lds() { return (size_t)T * K * 16 + 16 + 32 * 8 + 16 * 4; }
+
+// one workgroup of T threads per bucket of up to 4 T values; larger ones go to the work list of the second kernel.
+// Workgroups are dealt round-robin over the 8 XCDs: all buckets of one column go to workgroups of ONE XCD (column mod
+// 8), next to the tiles that filled them.
+template <int T>
+__global__ void __launch_bounds__(T) bhs_bucket_kernel(BhsArgs a) {
+    extern __shared__ uint64_t smem_bk[];
+    const int64_t k = (int64_t)(blockIdx.x >> 3);
+    const int64_t seg_x = (k / a.B) * 8 + (blockIdx.x & 7);
+    if (seg_x >= a.segs) return;
+    const BucketRef r = bucket_ref(a, seg_x * a.B + k % a.B);
+    if (r.n_b <= 4 * T && r.n_b <= a.reg_cap) bucket_wg_rank<T, 4>(a, r, smem_bk);
+    else if (threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1u)] = seg_x * a.B + k % a.B;
 }
 
+// the listed buckets in turn: up to 2048 values by the workgroup (8 per thread), beyond that (or beyond bh.reg_cap) by
+// its first wave in HBM.  (Workgroups of 512 / 1024 threads for the large buckets were measured: the barriers between
+// the phases cost more than the larger bucket saves -- DESIGN.md appendix A.4.)
 __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int x = (int)(blockIdx.x & 7);
-    const unsigned n_big = a.big_count[x];
-    const unsigned waves = (gridDim.x >> 3) * 4;
-    const int64_t* list = a.big_list + (int64_t)x * a.big_region;
+    extern __shared__ uint64_t smem_bk[];
+    const unsigned n_big = *a.big_count;
 #pragma nounroll
-    for (unsigned w = (blockIdx.x >> 3) * 4 + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); w < n_big; w += waves) {
-        const BucketRef r = bucket_ref(a, list[w]);
-        if (r.n_b > a.reg_cap && !r.pd) bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
-        else if (r.n_b <= 256) bucket_in_regs<4>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
-        else if (r.n_b <= 512) bucket_in_regs<8>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
-        else if (r.n_b <= 1024) bucket_in_regs<16>(a, r.ks, r.is, r.pd, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
-        else bucket_in_hbm(a, r.ks, r.is, r.n_b, r.seg_off, r.start, r.b, lane, r.bm);
+    for (unsigned w = blockIdx.x; w < n_big; w += gridDim.x) {
+        const BucketRef r = bucket_ref(a, a.big_list[w]);
+        if ((r.n_b > a.reg_cap && !r.pd) || r.n_b > 2048) {
+            if (threadIdx.x < 64) bucket_in_hbm(a, r.ks, r.n_b, r.start, (int)threadIdx.x, r.bm);
+        } else {
+            bucket_wg_rank<256, 8>(a, r, smem_bk);
+        }
+        __syncthreads();
     }
 }
 
@@ -629,26 +655,53 @@ __global__ void __launch_bounds__(256) bhs_suffix_kernel(BhsArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- 7. transpose back + final minimum
-// out[r * out_pitch + c] = min(q_cm[c][r], sfx[c][bid_cm[c][r]], 1)
-__global__ void __launch_bounds__(256) bhs_finish_kernel(BhsArgs a, double* __restrict__ out, int64_t out_pitch) {
-    __shared__ double tile[32][33];
-    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        const int64_t c = c0 + k, r = r0 + tx;
-        if (c < a.segs && r < a.m) {
-            const uint64_t own = a.q_cm[c * a.m + r];
-            const uint64_t later = a.sfx[c * a.B + a.bid_cm[c * a.m + r]];
-            double v = __longlong_as_double((long long)(own < later ? own : later));
-            if (v > 1.0) v = 1.0;
-            tile[k][tx] = v;
-        }
+// ---------------------------------------------------------------- 7. transpose back + final minimum, gathering
+// out[r * pitch + c] = min(result of value (r, c) in its slot, sfx[c][its bucket], 1).  A workgroup owns COLS columns x
+// 2048 / COLS rows: pos is read in runs per column, the results are gathered (8-byte reads inside the column's m x 8
+// bytes: L2 hits while the strip's workgroups -- consecutive on one XCD -- are at work), rows leave as 8 COLS-byte pieces.
+template <int COLS, bool NT>
+__global__ void __launch_bounds__(TC_T) bhs_finish_kernel(BhsArgs a, double* __restrict__ out, int row_tiles) {
+    constexpr int ROWS = 2048 / COLS;
+    __shared__ double tile[COLS][ROWS + 1];
+    const int tid = threadIdx.x;
+    // blocks are dealt round-robin over the XCDs: strip = (k / row_tiles) * 8 + xcd, row tile = k mod row_tiles
+    const int64_t k = (int64_t)(blockIdx.x >> 3);
+    const int64_t strip = (k / row_tiles) * 8 + (blockIdx.x & 7);
+    const int64_t c0 = strip * COLS;
+    if (c0 >= a.segs) return;
+    const int ncol = (int)min((int64_t)COLS, (int64_t)a.segs - c0);
+    const int64_t r0 = (k % row_tiles) * ROWS;
+    const int nrow = (int)min((int64_t)ROWS, a.m - r0);
+    constexpr int PER = 2048 / TC_T;                                  // 8 values per thread
+    unsigned pw[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * TC_T, c = i / ROWS, rr = i - c * ROWS;
+        const bool ok = c < ncol && rr < nrow;
+        pw[j] = ok ? (a.pos_cm ? __builtin_nontemporal_load(a.pos_cm + (c0 + c) * a.m + r0 + rr) : (unsigned)(r0 + rr)) : 0xFFFFFFFFu;
+    }
+    uint64_t own[PER], later[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = (tid + j * TC_T) / ROWS;
+        const bool ok = pw[j] != 0xFFFFFFFFu;
+        const uint64_t* src = a.keyS + (c0 + c) * a.m + (pw[j] & POS_MASK);
+        own[j] = ok ? (NT ? __builtin_nontemporal_load(src) : *src) : 0ull;
+        later[j] = ok ? a.sfx[(c0 + c) * a.B + (pw[j] >> POS_SHIFT)] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * TC_T, c = i / ROWS, rr = i - c * ROWS;
+        double v = __longlong_as_double((long long)(own[j] < later[j] ? own[j] : later[j]));
+        if (v > 1.0) v = 1.0;
+        tile[c][rr] = v;
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const int64_t r = r0 + k, c = c0 + tx;
-        if (c < a.segs && r < a.m) out[r * out_pitch + c] = tile[tx][k];
+    const int col = tid & (COLS - 1), rsub = tid / COLS;
+#pragma unroll
+    for (int j = 0; j < ROWS / (TC_T / COLS); ++j) {
+        const int rr = rsub + (TC_T / COLS) * j;
+        if (col < ncol && rr < nrow) out[(r0 + rr) * a.pitch + c0 + col] = tile[col][rr];
     }
 }
 
@@ -1138,35 +1191,43 @@ __global__ void __launch_bounds__(BHV_T) bhv_finish_kernel(BhvArgs a) {
 
 }  // namespace
 
-// scratch bytes the sample-sort path needs for `segs` segments of m values (without the transposed input)
+// scratch bytes the sample-sort path needs for `segs` columns of m values: transposed input (8 B per value), bucketed
+// keys / results (8), position words (4), the in-HBM path's copies (8), per-bucket tables
 size_t sd_bh_cols_scratch(int64_t m, int64_t segs) {
     const size_t vals = (size_t)m * (size_t)segs;
-    return vals * 22 + (size_t)segs * (size_t)(MAX_B + 1) * 48 + (1 << 16);
+    return vals * 28 + (size_t)segs * (size_t)(MAX_B + 1) * 50 + (1 << 16);
 }
 
 bool sd_bh_cols_supported(int64_t m, int64_t segs) {
-    return m >= 1 && m <= ((int64_t)1 << 18) && segs >= 1 && segs <= 0x7fffffff;
+    return m >= 1 && m <= ((int64_t)1 << POS_SHIFT) && segs >= 1 && segs <= 0x7fffffff;
 }
 
-// BH inside each of `segs` contiguous segments of d_cm ([segs][m]); the result goes, transposed back,
-// to d_out[r * out_pitch + c] (r < m, c < segs).  Scratch from the context arena (caller reserved it).
-int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double* d_cm, double* d_out, int64_t out_pitch) {
+// BH down each of the `segs` columns of the row-major table d_rm (m rows, row pitch `pitch` elements), in place.
+// Scratch from the context arena (caller reserved sd_bh_cols_scratch bytes).
+int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm, int64_t pitch) {
     Arena& A = ctx->arena;
     BhsArgs a;
-    a.p_cm = d_cm;
+    a.p_rm = d_rm;
+    a.pitch = pitch;
     a.m = m;
     a.segs = (int)segs;
+    // buckets: bh.wg threads per bucket workgroup (256 / 512 / 1024: buckets of up to 1024 / 2048 / 4096 values), mean bucket
+    // (bh.mean, default: half the workgroup's capacity)
+    int wg_threads = (int)ctx->param("bh.wg", 256);
+    wg_threads = wg_threads >= 1024 ? 1024 : wg_threads >= 512 ? 512 : 256;
     int B = 1;
-    if (m > 1024) {
-        // (mean bucket size, same process, 25 000 x 19 900: 96 -> 29.1 ms, 128 -> 23.6, 160 -> 23.3, 200 -> 22.0, 224 -> 28.2,
-        //  256 -> 35.4: per-bucket overhead below, the 8 / 16-keys-per-lane kernel for buckets beyond 256 values above)
-        int64_t mean = std::max<int64_t>(ctx->param("bh.mean", 200), sd_ceil_div(m, (int64_t)MAX_B));
+    if (m > 4 * (int64_t)wg_threads) {
+        int64_t mean = ctx->param("bh.mean", 0);
+        // (25 000 x 19 900, 256 threads: mean 400 / 450 / 512 / 600 -> 14.7 / 14.3 / 14.1 / 13.9 ms: fewer, fuller workgroups
+        //  against more buckets beyond the capacity, ~1 % at 0.55 of it)
+        if (mean <= 0) mean = wg_threads * 4 * 55 / 100;
+        mean = std::max<int64_t>(mean, sd_ceil_div(m, (int64_t)MAX_B));
         B = (int)sd_ceil_div(m, mean);
         if (B > MAX_B) B = MAX_B;
     }
     a.B = B;
     a.ablate = (int)ctx->param("bh.ablate", 0);
-    a.reg_cap = (int)std::min<int64_t>(1024, std::max<int64_t>(0, ctx->param("bh.reg_cap", 1024)));
+    a.reg_cap = (int)std::min<int64_t>(2048, std::max<int64_t>(0, ctx->param("bh.reg_cap", 2048)));
     a.spb = (int)ctx->param("bh.spb", 8);
     if (a.spb < 1) a.spb = 1;
     while (a.spb > 1 && (int64_t)a.spb * B > 8192) a.spb >>= 1;      // the sample is sorted in 96 KB of LDS
@@ -1176,23 +1237,29 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
     while (a.S2 < a.S) a.S2 <<= 1;
     const size_t vals = (size_t)m * (size_t)segs;
     const size_t sb = (size_t)segs * (size_t)B;
+    a.p_cm = (double*)A.alloc(vals * 8);
+    a.keyS = (uint64_t*)A.alloc(vals * 8);
     a.spl_k = (uint64_t*)A.alloc(sb * 8);
     a.bmin = (uint64_t*)A.alloc(sb * 8);
     a.sfx = (uint64_t*)A.alloc(sb * 8);
+    a.big_list = (int64_t*)A.alloc(sb * 8);
     a.spl_i = (uint32_t*)A.alloc(sb * 4);
     a.gcount = (unsigned*)A.alloc(sb * 4);
     a.cursor = (unsigned*)A.alloc(sb * 4);
     a.start = (unsigned*)A.alloc((size_t)segs * (size_t)(B + 1) * 4);
-    a.q_cm = (uint64_t*)A.alloc(vals * 8);
-    a.bid_cm = (uint16_t*)A.alloc(vals * 2);
-    a.big_region = sd_ceil_div(segs, (int64_t)8) * B;
-    a.big_list = (int64_t*)A.alloc((size_t)a.big_region * 8 * 8);
-    a.big_count = (unsigned*)A.alloc(32);
-    a.keyS = B > 1 ? (uint64_t*)A.alloc(vals * 8) : nullptr;
-    a.idxS = B > 1 ? (uint32_t*)A.alloc(vals * 4) : nullptr;
-    if (!a.spl_k || !a.bmin || !a.sfx || !a.spl_i || !a.gcount || !a.cursor || !a.start || !a.q_cm || !a.bid_cm || !a.big_list || !a.big_count ||
-        (B > 1 && (!a.keyS || !a.idxS)))
+    unsigned long long* zeroed = (unsigned long long*)A.alloc(16);    // spill_n | big_count
+    a.pos_cm = B > 1 ? (uint32_t*)A.alloc(vals * 4) : nullptr;
+    a.spill = B > 1 ? (uint64_t*)A.alloc(vals * 8) : nullptr;
+    if (!a.p_cm || !a.keyS || !a.spl_k || !a.bmin || !a.sfx || !a.big_list || !a.spl_i || !a.gcount || !a.cursor || !a.start || !zeroed ||
+        (B > 1 && (!a.pos_cm || !a.spill)))
         return SDICE_ERR_NOMEM;
+    a.spill_n = zeroed;
+    a.big_count = reinterpret_cast<unsigned*>(zeroed + 1);
+    SD_HIP(hipMemsetAsync(zeroed, 0, 16, ctx->stream));
+    const int64_t strips = sd_ceil_div(segs, (int64_t)TC_COLS);
+    SD_ARG(strips < ((int64_t)1 << 31), "bh: too many columns");
+    const int rows_per_block = (int)std::max<int64_t>(TC_ROWS, std::min<int64_t>(ctx->param("bh.rows_per_block", 2048), m));
+    const dim3 tgrid((unsigned)strips, (unsigned)sd_ceil_div(m, (int64_t)rows_per_block));
     if (B > 1) {
         SD_HIP(hipMemsetAsync(a.gcount, 0, sb * 4, ctx->stream));
         const size_t lds_s = (size_t)a.S2 * 12;
@@ -1203,34 +1270,51 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, const double*
         const int64_t tiles = sd_ceil_div(m, (int64_t)TILE);
         const int64_t tile_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * tiles;
         SD_ARG(tile_blocks < ((int64_t)1 << 31), "bh: too many tiles");
-        SD_LAUNCH(ctx, "bhs_count_kernel", (bhs_tile_kernel<false>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
+        // the splitters of a 16-column strip beside the transpose tile: up to ~190 buckets per column; beyond, the
+        // transpose runs alone and the tiles of the scatter kernel count first
+        const size_t lds_tc = (size_t)TC_COLS * ((size_t)(B - 1) * 12 + (size_t)B * 4);
+        if (lds_tc <= 48 * 1024 && ctx->param("bh.fused_count", 1)) {
+            SD_LAUNCH(ctx, "bhs_transpose_count_kernel", (bhs_transpose_kernel<true>), tgrid, dim3(TC_T), lds_tc, a, rows_per_block);
+        } else {
+            SD_LAUNCH(ctx, "bhs_transpose_kernel", (bhs_transpose_kernel<false>), tgrid, dim3(TC_T), 0, a, rows_per_block);
+            SD_LAUNCH(ctx, "bhs_count_kernel", (bhs_tile_kernel<false>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
+        }
         SD_LAUNCH(ctx, "bhs_scan_kernel", bhs_scan_kernel, dim3((unsigned)segs), dim3(256), 0, a);
         SD_LAUNCH(ctx, "bhs_scatter_kernel", (bhs_tile_kernel<true>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
+    } else {
+        SD_LAUNCH(ctx, "bhs_transpose_kernel", (bhs_transpose_kernel<false>), tgrid, dim3(TC_T), 0, a, rows_per_block);
     }
     const int64_t n_buckets = segs * B;
-    SD_ARG(sd_ceil_div(n_buckets, (int64_t)4) < ((int64_t)1 << 31), "bh: too many buckets");
-    SD_HIP(hipMemsetAsync(a.big_count, 0, 32, ctx->stream));
-    const int blocks_per_seg = (int)sd_ceil_div((int64_t)B, (int64_t)4);
-    const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * blocks_per_seg;
+    const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * B;
     SD_ARG(bucket_blocks < ((int64_t)1 << 31), "bh: too many buckets");
-    // bh.keys: keys per lane of the main bucket kernel (4: buckets of up to 256 values, 8: up to 512); larger buckets go
-    // to the (key, index) networks of the second kernel
-    if (ctx->param("bh.keys", 4) >= 8)
-        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<8>), dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
-    else
-        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<4>), dim3((unsigned)bucket_blocks), dim3(256), 0, a, blocks_per_seg);
-    // (a multiple of 8 workgroups, at least 8: workgroup w serves the list of XCD w mod 8)
-    const int64_t big_blocks = std::max<int64_t>(8, sd_ceil_div(std::min<int64_t>(sd_ceil_div(n_buckets, (int64_t)4), (int64_t)ctx->n_cu * 4), (int64_t)8) * 8);
-    SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel, dim3((unsigned)big_blocks), dim3(256), 0, a);
+    // threads of a bucket workgroup (4 values each): twice the mean bucket, so that ~1 % of the buckets (sizes ~ Gamma(8))
+    // overflow to the second kernel
+    if (wg_threads == 256) {
+        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<256>), dim3((unsigned)bucket_blocks), dim3(256), (bucket_wg_lds<256, 4>()), a);
+    } else if (wg_threads == 512) {
+        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<512>), dim3((unsigned)bucket_blocks), dim3(512), (bucket_wg_lds<512, 4>()), a);
+    } else {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bhs_bucket_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)bucket_wg_lds<1024, 4>()));
+        SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<1024>), dim3((unsigned)bucket_blocks), dim3(1024), (bucket_wg_lds<1024, 4>()), a);
+    }
+    const int64_t big_blocks = std::max<int64_t>(1, std::min<int64_t>(n_buckets, (int64_t)ctx->n_cu * 4));
+    SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel, dim3((unsigned)big_blocks), dim3(256), (bucket_wg_lds<256, 8>()), a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);
-    const int64_t gx = sd_ceil_div(m, (int64_t)32);
-    for (int64_t c0 = 0; c0 < segs; c0 += (int64_t)65535 * 32) {
-        BhsArgs b = a;
-        const int64_t cc = std::min<int64_t>((int64_t)65535 * 32, segs - c0);
-        b.segs = (int)cc;
-        b.q_cm += c0 * m; b.bid_cm += c0 * m; b.sfx += c0 * B;
-        SD_LAUNCH(ctx, "bhs_finish_kernel", bhs_finish_kernel, dim3((unsigned)gx, (unsigned)sd_ceil_div(cc, (int64_t)32)),
-                  dim3(256), 0, b, d_out + c0, out_pitch);
+    // bh.finish_cols: columns per workgroup of the last kernel (16: full 128-byte lines out, 3.2 MB of results per strip
+    // at 25 000 rows; 8: half lines, half the L2 footprint of the gather); bh.finish_nt: non-temporal gather loads
+    const int fcols = ctx->param("bh.finish_cols", 16) >= 16 ? 16 : 8;
+    const bool fnt = ctx->param("bh.finish_nt", 0) != 0;
+    const int64_t fstrips = sd_ceil_div(segs, (int64_t)fcols);
+    const int64_t row_tiles = sd_ceil_div(m, (int64_t)(2048 / fcols));
+    const int64_t fin_blocks = sd_ceil_div(fstrips, (int64_t)8) * 8 * row_tiles;
+    SD_ARG(fin_blocks < ((int64_t)1 << 31), "bh: too many tiles");
+    if (fcols == 16) {
+        if (fnt) SD_LAUNCH(ctx, "bhs_finish_kernel", (bhs_finish_kernel<16, true>), dim3((unsigned)fin_blocks), dim3(TC_T), 0, a, d_rm, (int)row_tiles);
+        else SD_LAUNCH(ctx, "bhs_finish_kernel", (bhs_finish_kernel<16, false>), dim3((unsigned)fin_blocks), dim3(TC_T), 0, a, d_rm, (int)row_tiles);
+    } else {
+        if (fnt) SD_LAUNCH(ctx, "bhs_finish_kernel", (bhs_finish_kernel<8, true>), dim3((unsigned)fin_blocks), dim3(TC_T), 0, a, d_rm, (int)row_tiles);
+        else SD_LAUNCH(ctx, "bhs_finish_kernel", (bhs_finish_kernel<8, false>), dim3((unsigned)fin_blocks), dim3(TC_T), 0, a, d_rm, (int)row_tiles);
     }
     return SDICE_OK;
 }

@@ -657,19 +657,22 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 }
 
 // Exclusive prefix of `agg` over the tiles before `tile` (called by the 64 lanes of one wave).
-// Tile = workgroup id.  A workgroup publishes its aggregate before it waits for anything, and each
-// XCD starts its workgroups in increasing id order, so the smallest unfinished tile is always running
-// and every wait ends; HIP does not promise that order, hence the spin is bounded: a wait that
-// outlasts ~1 s gives up, flags ST_LOOKBACK (the chain's result is then discarded and the caller
-// falls back to the generic path) and the grid drains.  (A device-side ticket would turn the order into a guarantee; it was
-// measured: one atomic counter hands out ~90 tickets per microsecond, and a ticket per tile alone bounded this kernel at
-// 22 us for 1 954 tiles, a third of its run time -- DESIGN.md, Appendix A.2.)
+// Forward progress: the neighbour kernel is launched with AT MOST as many workgroups as the device holds at once
+// (launch_neighbours: occupancy x CUs), and a workgroup takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... in
+// increasing order, publishing a tile's aggregate before it waits for anything.  Every workgroup of the grid is resident
+// at some point and stays until it is through its tiles, so the owner of the smallest unfinished tile is either running
+// or about to be dispatched into a slot that only workgroups of OTHER kernels can be holding -- it never waits on an
+// unfinished tile, and every wait ends whatever order the dispatcher chooses.  (Rounds 1-3 launched one workgroup per tile
+// and relied on in-order dispatch; a device-side ticket would also do, measured at 22 us per 1 954 tiles.)  The spin stays
+// bounded all the same: a wait that outlasts ~1 s gives up, flags ST_LOOKBACK (the chain's result is then discarded: the
+// synchronous caller falls back to the generic path, the asynchronous one reports it at the next sync) and the grid drains.
+// fail: cluster.ablate & 256 (tests; the one ablation bit that is compiled into the shipped kernel): tile 1 gives up at once.
 __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* state, int tile, unsigned long long agg,
-                                                                 int lane, unsigned long long* sb) {
+                                                                 int lane, unsigned long long* sb, bool fail) {
     if (lane == 0) st_agent(&state[tile], (tile == 0 ? LB_P : LB_A) | agg);
     unsigned long long excl = 0;
     int idx = tile - 1;
-    unsigned spins = 0;
+    unsigned spins = fail && tile == 1 ? (1u << 21) : 0u;
     while (idx >= 0) {
         const int j = idx - lane;
         const unsigned long long v = j >= 0 ? ld_agent(&state[j]) : LB_P;
@@ -678,7 +681,7 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
         const unsigned long long pm = __ballot(flag == 2u);
         const int first_p = pm ? __ffsll((long long)pm) - 1 : 64;
         const unsigned long long need = first_p >= 63 ? ~0ull : ((1ull << (first_p + 1)) - 1ull);
-        if (empty & need) {
+        if ((empty & need) || (fail && tile == 1)) {
             if (++spins > (1u << 21)) {
                 if (lane == 0) { atomicOr(&sb[SB_FLAGS], (unsigned long long)ST_LOOKBACK); atomicOr(&sb[SB_STICKY], (unsigned long long)ST_LOOKBACK); }
                 break;
@@ -761,14 +764,18 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = (int)a.n;
     const int n_tiles = (n + T - 1) / T;
-    const int tile = blockIdx.x;
+    const bool failed_chain = (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW | ST_DUP)) != 0;
+    // a workgroup takes its tiles in increasing order (see lookback_exclusive)
+#pragma nounroll
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (tile != (int)blockIdx.x) __syncthreads();          // (the previous tile's readers are done with the LDS)
     const int t0 = tile * T;
     const int nr = min(T, n - t0);
-    if (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW | ST_DUP)) {
+    if (failed_chain) {
         // failed chain: leave an all-zero row_ptr (every list empty) so that a dependent launch stays in bounds
         if (t < nr) { a.row_ptr[t0 + t] = 0; if ((t & 15) == 0) a.blkneed[(t0 + t) >> 4] = 0; }
         if (t0 + t == 0) a.row_ptr[n] = 0;
-        return;
+        continue;
     }
     if (t == 0) s_misc[2] = 0;
     if (t < 64) {
@@ -948,7 +955,7 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     for (int k = 0; k < T / 64; ++k) { const uint32_t v = wsum[k]; if (k < w) wbase += v; total += v; }
     const uint32_t loff = wbase + x - deg;
     if (w == 0) {
-        const unsigned long long base = SD_ABL(a, 128) ? 0ull : lookback_exclusive(a.tile_state, tile, (unsigned long long)total, lane, a.sb);
+        const unsigned long long base = SD_ABL(a, 128) ? 0ull : lookback_exclusive(a.tile_state, tile, (unsigned long long)total, lane, a.sb, (a.ablate & 256) != 0);
         if (lane == 0) {
             s_base = base;
             if (s_misc[2]) atomicMax(&a.sb[SB_REACH + (tile % SB_SLOTS)], (unsigned long long)s_misc[2]);
@@ -981,6 +988,7 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
         walk_back_global(a, r - 1, c, l, st, maxlen, put);
         walk_fwd_global(a, r + 1, n, c, rgt, st, put);
     }
+    }   // tile loop
 }
 
 inline unsigned grid_for(int64_t n, int threads) { return (unsigned)sd_ceil_div(n, threads); }
@@ -1062,7 +1070,18 @@ int launch_neighbours(sdice_ctx* ctx, FastPlan& pl) {
     pl.a.col = ctx->d_col;
     pl.a.col_cap = ctx->col_cap;
     pl.a.blkneed = ctx->d_reach;
-    SD_LAUNCH(ctx, "neighbours_kernel", (neighbours_kernel<NB_T>), dim3((unsigned)pl.n_tiles), dim3(NB_T), 0, pl.a);
+    // at most as many workgroups as the device holds at once (what the look-back's forward progress rests on); cluster.nb_grid
+    // overrides it downwards (tests: a handful of workgroups walking many tiles each)
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int occ = 0;
+        SD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(neighbours_kernel<NB_T>), NB_T, 0));
+        per_cu = occ > 0 ? occ : 1;
+    }
+    int64_t grid = std::min<int64_t>(pl.n_tiles, (int64_t)per_cu * ctx->n_cu);
+    const int64_t forced = ctx->param("cluster.nb_grid", 0);
+    if (forced > 0) grid = std::min<int64_t>(grid, forced);
+    SD_LAUNCH(ctx, "neighbours_kernel", (neighbours_kernel<NB_T>), dim3((unsigned)std::max<int64_t>(grid, 1)), dim3(NB_T), 0, pl.a);
     return SDICE_OK;
 }
 

@@ -107,18 +107,45 @@ extern "C" int sdice_comm_destroy(sdice_ctx* ctx) {
     return SDICE_OK;
 }
 
+// Collectives beside compute: between sdice_comm_fork and sdice_comm_join the collectives of this context are enqueued
+// on a SECOND stream.  fork: that stream waits for everything enqueued on the main stream so far (call it again before
+// each collective whose input the main stream has just produced); join: the main stream waits for the collectives issued
+// since, and collectives go back to the main stream.  (`pairwise`, correction per pair column: the all-to-all that takes
+// a column group's corrected values home runs while the next group is being corrected.)
+extern "C" int sdice_comm_fork(sdice_ctx* ctx) {
+    SD_ARG(ctx, "ctx is NULL");
+    SD_HIP(hipSetDevice(ctx->device));
+    if (!ctx->comm_stream) {
+        SD_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        SD_HIP(hipEventCreateWithFlags(&ctx->comm_ev, hipEventDisableTiming));
+    }
+    SD_HIP(hipEventRecord(ctx->comm_ev, ctx->stream));
+    SD_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev, 0));
+    ctx->comm_forked = true;
+    return SDICE_OK;
+}
+
+extern "C" int sdice_comm_join(sdice_ctx* ctx) {
+    SD_ARG(ctx, "ctx is NULL");
+    if (!ctx->comm_forked) return SDICE_OK;
+    SD_HIP(hipEventRecord(ctx->comm_ev, ctx->comm_stream));
+    SD_HIP(hipStreamWaitEvent(ctx->stream, ctx->comm_ev, 0));
+    ctx->comm_forked = false;
+    return SDICE_OK;
+}
+
 extern "C" int sdice_allgather_dev(sdice_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank) {
     SD_ARG(ctx && bytes_per_rank >= 0, "bad arguments");
     if (bytes_per_rank == 0) return SDICE_OK;
     SD_ARG(d_send && d_recv, "NULL pointer");
     if (ctx->world == 1 && !ctx->comm) {
         if ((const void*)d_send != d_recv)
-            SD_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+            SD_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, ctx->coll_stream()));
         return SDICE_OK;
     }
     SD_ARG(ctx->comm, "communicator not initialised (sdice_comm_init)");
     int tok = sd_prof_begin(ctx, "rccl_allgather");
-    const int rc = g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, 0 /* ncclInt8 */, ctx->comm, ctx->stream);
+    const int rc = g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, 0 /* ncclInt8 */, ctx->comm, ctx->coll_stream());
     sd_prof_end(ctx, tok);
     if (rc != 0) return nccl_fail("ncclAllGather", rc);
     return SDICE_OK;
@@ -132,7 +159,7 @@ extern "C" int sdice_alltoall_dev(sdice_ctx* ctx, const void* d_send, void* d_re
     if (bytes_per_peer == 0) return SDICE_OK;
     SD_ARG(d_send && d_recv && d_send != d_recv, "NULL or aliased buffers");
     if (ctx->world == 1 && !ctx->comm) {
-        SD_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, ctx->stream));
+        SD_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, ctx->coll_stream()));
         return SDICE_OK;
     }
     SD_ARG(ctx->comm, "communicator not initialised (sdice_comm_init)");
@@ -140,10 +167,10 @@ extern "C" int sdice_alltoall_dev(sdice_ctx* ctx, const void* d_send, void* d_re
     int rc = g_rccl.GroupStart();
     for (int q = 0; q < ctx->world && rc == 0; ++q) {
         rc = g_rccl.Send((const char*)d_send + (size_t)q * bytes_per_peer, (size_t)bytes_per_peer, 0 /* ncclInt8 */, q,
-                         ctx->comm, ctx->stream);
+                         ctx->comm, ctx->coll_stream());
         if (rc == 0)
             rc = g_rccl.Recv((char*)d_recv + (size_t)q * bytes_per_peer, (size_t)bytes_per_peer, 0, q, ctx->comm,
-                             ctx->stream);
+                             ctx->coll_stream());
     }
     const int rc_end = g_rccl.GroupEnd();
     sd_prof_end(ctx, tok);

@@ -102,6 +102,10 @@ struct sdice_ctx {
     void* rccl_lib = nullptr;
     void* comm = nullptr;
     int rank = 0, world = 1;
+    hipStream_t comm_stream = nullptr;   // second stream for collectives between sdice_comm_fork and sdice_comm_join
+    hipEvent_t comm_ev = nullptr;
+    bool comm_forked = false;
+    hipStream_t coll_stream() const { return comm_forked ? comm_stream : stream; }
 
     int64_t param(const char* name, int64_t dflt) const {
         auto it = params.find(name);

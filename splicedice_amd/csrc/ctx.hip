@@ -135,6 +135,8 @@ extern "C" int sdice_ctx_destroy(sdice_ctx* ctx) {
     if (ctx->cluster_sb) (void)hipFree(ctx->cluster_sb);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     ctx->arena.release();
+    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->comm_ev) (void)hipEventDestroy(ctx->comm_ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SDICE_OK;
@@ -142,6 +144,7 @@ extern "C" int sdice_ctx_destroy(sdice_ctx* ctx) {
 
 extern "C" int sdice_sync(sdice_ctx* ctx) {
     SD_ARG(ctx, "ctx is NULL");
+    if (ctx->comm_forked) SD_TRY(sdice_comm_join(ctx));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return sd_cluster_resolve(ctx);      // (reports the deferred status of an asynchronous clustering)
 }
@@ -334,8 +337,8 @@ extern "C" int sdice_timer_stop(sdice_ctx* ctx, double* elapsed_ms) {
 extern "C" int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value) {
     SD_ARG(ctx && name, "bad arguments");
     static const char* known[] = {"ps.lds_bytes", "ps.tile_rows", "ps.threads", "ps.chunk_cols",
-                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "cluster.max_nnz", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "ps.gen1", "ps.use_reach", "sort.rounds", "ranksum.variant", "ranksum.ablate",
-                                  "fisher.table_max", "fisher.refill", "fisher.unroll", "fisher.count_steps", "bh.columns_path", "bh.vector_path", "bhv.mean", "bhv.cap", "bh.reg_cap", "bh.mean", "bh.keys", "bh.ablate", "bh.spb", nullptr};
+                                  "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.nb_grid", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "cluster.max_nnz", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "ps.gen1", "ps.use_reach", "sort.rounds", "ranksum.variant", "ranksum.ablate",
+                                  "fisher.table_max", "fisher.refill", "fisher.unroll", "fisher.count_steps", "bh.columns_path", "bh.vector_path", "bhv.mean", "bhv.cap", "bh.reg_cap", "bh.mean", "bh.keys", "bh.ablate", "bh.rows_per_block", "bh.fused_count", "bh.finish_cols", "bh.finish_nt", "bh.wg", "bh.spb", nullptr};
     for (int i = 0; known[i]; ++i)
         if (strcmp(known[i], name) == 0) {
             ctx->params[name] = value;

@@ -348,8 +348,13 @@ __global__ void __launch_bounds__(256) ranksum_pair_kernel(const float* __restri
 //     here): the numpy pairwise sum runs over them in original order, medians are those of the middle keys.
 // A row holding any value that is not exactly float32(k / 1000) is marked RS_REDO and left to ranksum_wave_kernel.
 constexpr unsigned char RS_REDO_Q = 0xFF;       // (same mark as RS_REDO below)
-constexpr int RSQ_G2 = 64;                      // u16 offset of group 2 inside a staged row
-constexpr int RSQ_STRIDE = 130;                 // u16 per staged row: 65 dwords
+// layout of a staged row in dwords: group 1 in [0, 32), one spare, group 2 in [33, 65), one spare: row pitch 66.  ds_read_b32
+// and every ds_write bank by (dword address) mod 32 and serve lanes 0..31 and 32..63 as separate groups (MI355X_MICROARCH.md,
+// LDS): lane (row r, group g) reading dword idx of its group sits in bank (2 r + g + idx) mod 32 -- the 16 rows x 2 groups of
+// a half wave in 32 different banks.  (Rounds 2-3 had group 2 at dword 32 and pitch 65, planned for 64 banks: every
+// per-lane access of the two lanes of a row met in ONE bank, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.57.)
+constexpr int RSQ_G2 = 66;                      // u16 offset of group 2 inside a staged row
+constexpr int RSQ_STRIDE = 132;                 // u16 per staged row: 66 dwords
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 typedef uint32_t __attribute__((may_alias)) u32_alias;      // dword view of the staged 16-bit keys
 
@@ -443,10 +448,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             const int sel1 = act1 ? selL[selbase + e1] : 0;
             u32_alias* tile32 = reinterpret_cast<u32_alias*>(tile);
             const int pitch32 = stride >> 1;
-            // group 1 at the start of the row, group 2 at u16 offset 64: with a row pitch of 65 dwords the 32 rows x 2
-            // groups of a wave sit in 64 different banks (r and r + 32) whenever the lanes read the same element
-            // index -- the packed layout (group 2 right behind group 1, odd pitch) lost 47 % of its LDS cycles to
-            // bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+            // group 1 at the start of the row, group 2 at dword 33, row pitch 66 dwords (see RSQ_G2)
             constexpr int RB = 16;
             for (int r0 = 0; r0 < 32; r0 += RB) {
                 float x0[RB], x1[RB];
@@ -471,7 +473,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const bool bad0 = act0 && !nan0 && ps_of_key(kf0) != a0, bad1 = act1 && !nan1 && ps_of_key(kf1) != a1;
                     if (__ballot(bad0 || bad1)) redo_rows |= 1u << r;
                     const uint32_t kk0 = (act0 && !nan0) ? (uint32_t)k0 : 0xFFFFu, kk1 = (act1 && !nan1) ? (uint32_t)k1 : 0xFFFFu;
-                    tile32[r * pitch32 + lane] = kk0 | (kk1 << 16);
+                    tile32[r * pitch32 + lane + (lane >> 5)] = kk0 | (kk1 << 16);      // (group 2 starts at dword 33)
                 }
             }
         }

@@ -17,7 +17,9 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <memory>
 #include <mutex>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include <fcntl.h>
@@ -27,6 +29,15 @@
 #include "sdice.h"
 
 void sdice_set_error(const char* fmt, ...);
+
+// seconds spent formatting / writing and bytes written by the table writers since the last reset (a measurement aid of
+// tools/bench_cli.py; the calling thread's totals)
+static thread_local double g_io_stats[3] = {0.0, 0.0, 0.0};
+extern "C" int sdice_textio_stats(double* out3, int reset) {
+    if (out3) { out3[0] = g_io_stats[0]; out3[1] = g_io_stats[1]; out3[2] = g_io_stats[2]; }
+    if (reset) g_io_stats[0] = g_io_stats[1] = g_io_stats[2] = 0.0;
+    return SDICE_OK;
+}
 
 namespace {
 
@@ -116,6 +127,73 @@ inline void put_repr(std::string& out, T x) {
     }
 }
 
+// numpy str(float32 / float64) straight into a character buffer (at most 26 characters): the rule of put_repr on raw
+// pointers -- the per-character std::string appends of put_repr were two thirds of the time of the `pairwise` writer
+template <typename T>
+inline char* repr_to(char* o, T x) {
+    if (std::isnan(x)) { memcpy(o, "nan", 3); return o + 3; }
+    if (std::isinf(x)) { if (x < 0) *o++ = '-'; memcpy(o, "inf", 3); return o + 3; }
+    if (x == 0) { if (std::signbit(x)) *o++ = '-'; memcpy(o, "0.0", 3); return o + 3; }
+    char sci[48];
+    auto r = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX[X], shortest
+    const char* p = sci;
+    if (*p == '-') *o++ = *p++;
+    const char* e = r.ptr - 1;
+    while (*e != 'e') --e;
+    int a = 0;
+    for (const char* q = e + 2; q < r.ptr; ++q) a = a * 10 + (*q - '0');
+    const int exp10 = e[1] == '-' ? -a : a;
+    const char d0 = p[0];
+    const char* frac = p + 2;
+    const int nf = p[1] == '.' ? (int)(e - frac) : 0;            // digits behind the point
+    if (exp10 >= -4 && exp10 < 16) {
+        if (exp10 >= 0) {
+            *o++ = d0;
+            const int take = nf < exp10 ? nf : exp10;
+            memcpy(o, frac, (size_t)take); o += take;
+            for (int i = take; i < exp10; ++i) *o++ = '0';
+            *o++ = '.';
+            if (nf > exp10) { memcpy(o, frac + exp10, (size_t)(nf - exp10)); o += nf - exp10; }
+            else *o++ = '0';
+        } else {
+            *o++ = '0'; *o++ = '.';
+            for (int i = 0; i < -exp10 - 1; ++i) *o++ = '0';
+            *o++ = d0;
+            memcpy(o, frac, (size_t)nf); o += nf;
+        }
+    } else {
+        *o++ = d0;
+        if (nf) { *o++ = '.'; memcpy(o, frac, (size_t)nf); o += nf; }
+        *o++ = 'e';
+        *o++ = exp10 < 0 ? '-' : '+';
+        if (a < 10) *o++ = '0';
+        auto r2 = std::to_chars(o, o + 8, a);
+        o = r2.ptr;
+    }
+    return o;
+}
+
+// worker threads by default: the hardware's, capped by the cgroup's CPU quota (a one-GPU box of the pool reports 256 hardware
+// threads and grants 16 cores: 64 formatter threads on 16 cores ran slower than 16)
+inline int default_threads() {
+    static const int cached = [] {
+        int n = (int)std::thread::hardware_concurrency();
+        if (n < 1) n = 1;
+        FILE* fh = fopen("/sys/fs/cgroup/cpu.max", "r");
+        if (fh) {
+            char q[32] = {0};
+            long long period = 0;
+            if (fscanf(fh, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long long quota = atoll(q);
+                if (quota > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+            }
+            fclose(fh);
+        }
+        return n < 1 ? 1 : n;
+    }();
+    return cached;
+}
+
 // An exception inside a worker (std::bad_alloc from a growing row buffer) or from a thread that cannot be started
 // must not reach std::terminate: workers catch into `err`, every started thread is joined, the first exception is
 // rethrown on the caller's thread (the extern "C" function-try-blocks map it to SDICE_ERR_*).
@@ -123,7 +201,7 @@ template <typename F>
 void parallel_rows(int64_t n, int threads, F&& fn) {
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
-    if (n < 4096) threads = 1;
+    if (n < threads) threads = (int)std::max<int64_t>(n, 1);      // (the CALLER decides whether the work is worth threads)
     if (threads == 1) { fn(0, 0, n); return; }
     std::vector<std::thread> pool;
     std::exception_ptr err;
@@ -169,51 +247,74 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
     fwrite(header, 1, strlen(header), fh);
     // rows are formatted in blocks so that memory stays bounded and the writes stay ordered
     const int64_t block = 1 << 16;
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    std::vector<std::string> bufs;
+    int nthreads = threads > 0 ? threads : default_threads();
     for (int64_t r0 = 0; r0 < n; r0 += block) {
         const int64_t nb = std::min(block, n - r0);
-        int used = nb < 4096 ? 1 : std::min(nthreads, 64);
+        // threads by CELLS, not rows: a `pairwise` slab is ~1 700 rows of 19 900 columns (deciding by rows left that
+        // writer on ONE thread: 1.5e7 values/s through the CLI in round 3)
+        int used = nb * (int64_t)std::max(s, 1) < 65536 ? 1 : std::min(nthreads, 64);
         if (used < 1) used = 1;
-        bufs.assign(used, std::string());
+        if ((int64_t)used > nb) used = (int)nb;
+        std::vector<std::unique_ptr<char[]>> raws((size_t)used);
+        std::vector<size_t> lens((size_t)used, 0);
+        const auto t_fmt = std::chrono::steady_clock::now();
         parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
-            std::string& out = bufs[t];
-            out.reserve((size_t)(b - a) * ((size_t)s * 8 + 32));
+            // worst case per cell: tab + 26 characters (numpy repr of a double, '%.3f' / '%.0f' of a count or PS value
+            // below 1e21; anything longer takes the slow path through a temporary) -- written with a bare pointer
+            size_t cap = (size_t)(name_off[r0 + b] - name_off[r0 + a]) + (size_t)(b - a) * ((size_t)s * 27 + 1) + 64;
+            std::unique_ptr<char[]> raw(new char[cap]);
+            char* o = raw.get();
+            std::string tmp;
             for (int64_t r = r0 + a; r < r0 + b; ++r) {
-                out.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+                const size_t nl = (size_t)(name_off[r + 1] - name_off[r]);
+                memcpy(o, names + name_off[r], nl); o += nl;
                 for (int32_t c = 0; c < s; ++c) {
-                    out += '\t';
+                    *o++ = '\t';
                     const size_t i = (size_t)r * (size_t)s + (size_t)c;
                     if (dtype == 2) {
-                        char b2[16];
-                        auto rr = std::to_chars(b2, b2 + sizeof(b2), ((const int32_t*)data)[i]);
-                        out.append(b2, rr.ptr - b2);
-                    } else if (dtype == 0) {
-                        const float v = ((const float*)data)[i];
-                        if (mode == 0) put_fixed3(out, (double)v);
-                        else if (mode == 1) put_fixed0(out, (double)v);
-                        else put_repr<float>(out, v);
+                        auto rr = std::to_chars(o, o + 16, ((const int32_t*)data)[i]);
+                        o = rr.ptr;
+                    } else if (mode == 2) {
+                        o = dtype == 0 ? repr_to<float>(o, ((const float*)data)[i]) : repr_to<double>(o, ((const double*)data)[i]);
                     } else {
-                        const double v = ((const double*)data)[i];
-                        if (mode == 0) put_fixed3(out, v);
-                        else if (mode == 1) put_fixed0(out, v);
-                        else put_repr<double>(out, v);
+                        const double v = dtype == 0 ? (double)((const float*)data)[i] : ((const double*)data)[i];
+                        tmp.clear();
+                        if (mode == 0) put_fixed3(tmp, v); else put_fixed0(tmp, v);
+                        if (tmp.size() > 26) {                      // (a count beyond 1e21: grow the buffer)
+                            const size_t used_b = (size_t)(o - raw.get());
+                            cap += tmp.size() + 64;
+                            std::unique_ptr<char[]> bigger(new char[cap + tmp.size()]);
+                            memcpy(bigger.get(), raw.get(), used_b);
+                            raw.swap(bigger);
+                            o = raw.get() + used_b;
+                        }
+                        memcpy(o, tmp.data(), tmp.size()); o += tmp.size();
                     }
                 }
-                out += '\n';
+                *o++ = '\n';
             }
+            lens[(size_t)t] = (size_t)(o - raw.get());
+            raws[(size_t)t] = std::move(raw);
         });
-        for (auto& b : bufs)
-            if (!b.empty() && fwrite(b.data(), 1, b.size(), fh) != b.size()) {
+        const auto t_wr = std::chrono::steady_clock::now();
+        for (int t = 0; t < used; ++t) {
+            if (lens[(size_t)t] && fwrite(raws[(size_t)t].get(), 1, lens[(size_t)t], fh) != lens[(size_t)t]) {
                 fclose(fh);
                 sdice_set_error("sdice_write_table: short write to %s", path);
                 return SDICE_ERR_ARG;
             }
+            g_io_stats[2] += (double)lens[(size_t)t];
+        }
+        const auto t_end = std::chrono::steady_clock::now();
+        g_io_stats[0] += std::chrono::duration<double>(t_wr - t_fmt).count();
+        g_io_stats[1] += std::chrono::duration<double>(t_end - t_wr).count();
     }
+    const auto t_cl = std::chrono::steady_clock::now();
     if (fclose(fh) != 0) {
         sdice_set_error("sdice_write_table: close failed for %s", path);
         return SDICE_ERR_ARG;
     }
+    g_io_stats[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cl).count();
     return SDICE_OK;
 } catch (const std::exception& e) {
     sdice_set_error("sdice_write_table: %s", e.what());
@@ -246,7 +347,7 @@ static int write_columns_impl(const char* path, const char* header, int64_t n, c
     }
     fwrite(header, 1, strlen(header), fh);
     const int64_t block = 1 << 16;
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : default_threads();
     std::vector<std::string> bufs;
     for (int64_t r0 = 0; r0 < n; r0 += block) {
         const int64_t nb = std::min(block, n - r0);
@@ -337,7 +438,7 @@ extern "C" int sdice_write_clusters(const char* path, int64_t n, const char* nam
         return SDICE_ERR_ARG;
     }
     const int64_t block = 1 << 16;
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : default_threads();
     std::vector<std::string> bufs;
     for (int64_t r0 = 0; r0 < n; r0 += block) {
         const int64_t nb = std::min(block, n - r0);
@@ -399,7 +500,7 @@ extern "C" int sdice_write_junction_bed(const char* path, int64_t n, const char*
         return SDICE_ERR_ARG;
     }
     const int64_t block = 1 << 18;
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : default_threads();
     std::vector<std::string> bufs;
     for (int64_t r0 = 0; r0 < n; r0 += block) {
         const int64_t nb = std::min(block, n - r0);
@@ -568,7 +669,7 @@ extern "C" int sdice_table_read(sdice_table* t, char* header, char* names, int64
     }
     if (t->n >= 0 && name_off) name_off[t->n] = off;
     std::vector<int64_t> bad((size_t)64, -1);
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : default_threads();
     if (nthreads > 64) nthreads = 64;
     parallel_rows(t->n, nthreads, [&](int tix, int64_t a, int64_t b) {
         for (int64_t i = a; i < b; ++i) {

@@ -427,13 +427,20 @@ class PairwiseShard:
     redundantly (sdice_bh_masked_dev); "none" needs no exchange.  bench.py --workload pairwise --gpus N times exactly
     this step."""
 
-    def __init__(self, engine, comm, n, s, plan, correction="pairwise", test="fisher"):
+    def __init__(self, engine, comm, n, s, plan, correction="pairwise", test="fisher", overlap_groups=None):
         self.e, self.comm, self.n, self.s, self.plan = engine, comm, n, s, plan
         self.correction, self.test = correction, test
         part = plan[comm.rank]
         self.lo, self.hi, self.elo = part["own_lo"], part["own_hi"], part["ext_lo"]
         self.k = self.hi - self.lo
         self.pairs = s * (s - 1) // 2
+        # the exchange that takes the corrected values home goes in G column groups: group g's all-to-all runs on the
+        # context's second stream (sdice_comm_fork) while group g + 1 is being corrected.  Every rank derives the same G.
+        ranges = pair_column_ranges(self.pairs, comm.world)
+        wmin = min(b - a for a, b in ranges) if self.pairs else 0
+        if overlap_groups is None:
+            overlap_groups = 1 if comm.world == 1 else min(4, max(1, wmin // 1024))
+        self.G = max(1, min(int(overlap_groups), max(wmin, 1))) if hasattr(engine, "comm_fork") else 1
         self.rows_of = [q["own_hi"] - q["own_lo"] for q in plan]
         self.maxk = max(max(self.rows_of), 1)
         self.d_p = engine.empty((max(self.k, 1), max(self.pairs, 1)), np.float64)
@@ -462,15 +469,25 @@ class PairwiseShard:
             maxw = max(max(b - a for a, b in ranges), 1)
             a, b = ranges[self.comm.rank]
             shape = (w, self.maxk, maxw)
-            self.bufs = dict(send=e.empty(shape, np.float64).zero(), back=e.empty(shape, np.float64).zero(),
+            # (G > 1: the way back is laid out [group][rank][row][column of the group], so that a group is one contiguous exchange)
+            gw = self._group_width(ranges)
+            shape2 = (self.G, w, self.maxk, gw) if self.G > 1 else shape
+            self.bufs = dict(send=e.empty(shape, np.float64).zero(), back=e.empty(shape2, np.float64).zero(),
                              mine=e.empty((max(self.n, 1), max(b - a, 1)), np.float64))
-            if w > 1:
-                self.bufs.update(got=e.empty(shape, np.float64), got2=e.empty(shape, np.float64))
+            if w > 1 or self.G > 1:
+                self.bufs.update(got=e.empty(shape, np.float64), got2=e.empty(shape2, np.float64))
         elif self.pairs and self.correction == "all":
             self.bufs = dict(pad=e.empty((self.maxk, self.pairs), np.float64),
                              d_q=e.empty((w * self.maxk, self.pairs), np.float64))
             if w > 1:
                 self.bufs["everything"] = e.empty((w * self.maxk, self.pairs), np.float64)
+
+    def _group_ranges(self, width):
+        """the G column groups of a rank that owns `width` pair columns: [(lo, hi)] relative to its first column"""
+        return [(g * width // self.G, (g + 1) * width // self.G) for g in range(self.G)]
+
+    def _group_width(self, ranges):
+        return max(max(hi - lo for lo, hi in self._group_ranges(b - a)) for a, b in ranges) if self.pairs else 1
 
     def _alltoall(self, x, into):
         if into is not None and hasattr(self.comm, "alltoall_into"):
@@ -511,17 +528,45 @@ class PairwiseShard:
                 if rows_of[r] and w:
                     e.copy2d_dev(mine.ptr + at * w * 8, w * 8, got.ptr + r * blk, maxw * 8, w * 8, rows_of[r])
                 at += rows_of[r]
-            if n and w:
-                e.bh_columns_dev(mine.offset(0, (n, w)))
-            at = 0
-            for r in range(comm.world):
-                if rows_of[r] and w:
-                    e.copy2d_dev(back.ptr + r * blk, maxw * 8, mine.ptr + at * w * 8, w * 8, w * 8, rows_of[r])
-                at += rows_of[r]
-            got2 = self._alltoall(back, self.bufs.get("got2"))
-            for q, (a, b) in enumerate(ranges):               # corrected values back into my rows
-                if k and b > a:
-                    e.copy2d_dev(d_p.ptr + a * 8, pairs * 8, got2.ptr + q * blk, maxw * 8, (b - a) * 8, k)
+            if self.G == 1:
+                if n and w:
+                    e.bh_columns_dev(mine.offset(0, (n, w)))
+                at = 0
+                for r in range(comm.world):
+                    if rows_of[r] and w:
+                        e.copy2d_dev(back.ptr + r * blk, maxw * 8, mine.ptr + at * w * 8, w * 8, w * 8, rows_of[r])
+                    at += rows_of[r]
+                got2 = self._alltoall(back, self.bufs.get("got2"))
+                for q, (a, b) in enumerate(ranges):               # corrected values back into my rows
+                    if k and b > a:
+                        e.copy2d_dev(d_p.ptr + a * 8, pairs * 8, got2.ptr + q * blk, maxw * 8, (b - a) * 8, k)
+            else:
+                # column groups: correct group g, pack it, send it home on the second stream while group g + 1 is corrected
+                gw = self._group_width(ranges)
+                blkg = maxk * gw * 8
+                got2 = self.bufs["got2"]
+                for g, (ga, gb) in enumerate(self._group_ranges(w)):
+                    if n and gb > ga:
+                        e.bh_columns_pitched_dev(mine.offset(ga, (n, gb - ga)), n, gb - ga, w)
+                    at = 0
+                    for r in range(comm.world):
+                        if rows_of[r] and gb > ga:
+                            e.copy2d_dev(back.ptr + (g * comm.world + r) * blkg, gw * 8, mine.ptr + (at * w + ga) * 8, w * 8,
+                                         (gb - ga) * 8, rows_of[r])
+                        at += rows_of[r]
+                    e.comm_fork()                                 # the second stream waits for the group's packing ...
+                    view_s = back.offset(g * comm.world * maxk * gw, (comm.world, maxk, gw))
+                    view_r = got2.offset(g * comm.world * maxk * gw, (comm.world, maxk, gw))
+                    if hasattr(comm, "alltoall_into"):
+                        comm.alltoall_into(view_s, view_r)        # ... and carries it while the main stream goes on
+                    else:
+                        e.copy2d_dev(view_r.ptr, view_s.nbytes, view_s.ptr, view_s.nbytes, view_s.nbytes, 1)
+                e.comm_join()
+                for q, (a, b) in enumerate(ranges):               # corrected values back into my rows
+                    for g, (ga, gb) in enumerate(self._group_ranges(b - a)):
+                        if k and gb > ga:
+                            e.copy2d_dev(d_p.ptr + (a + ga) * 8, pairs * 8, got2.ptr + (g * comm.world + q) * blkg, gw * 8,
+                                         (gb - ga) * 8, k)
         elif self.correction == "all" and pairs > 0:
             pad, d_q = self.bufs["pad"].memset(0xBF), self.bufs["d_q"]     # 0xBFBF... is a negative double: "absent"
             if k:
@@ -563,8 +608,8 @@ class PairwiseShard:
         self.bufs = {}
 
 
-def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, test="fisher", junctions=None):
-    sh = PairwiseShard(engine, comm, n, ext.shape[1], plan, correction, test)
+def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, test="fisher", junctions=None, overlap_groups=None):
+    sh = PairwiseShard(engine, comm, n, ext.shape[1], plan, correction, test, overlap_groups=overlap_groups)
     try:
         sh.load(ext, rp, cl, junctions=junctions)
         sh.step()
@@ -574,7 +619,7 @@ def _pairwise_dev(engine, comm, ext, rp, cl, a0, k, plan, n, pairs, correction, 
 
 
 def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwise", plan=None, test="fisher",
-                     junctions_ext=None):
+                     junctions_ext=None, overlap_groups=None):
     """`pairwise` with junction rows sharded over ranks.
 
     counts_ext: int32 rows [ext_lo, ext_hi) of this rank's shard in row order; CSR over all rows.
@@ -584,7 +629,8 @@ def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwis
     chi-square of --chi2 (pairwise_fisher.py:133-136) on the same shards; a table with a zero expected frequency anywhere
     aborts the run on every rank, as the reference's chi2_contingency does.
     junctions_ext (with plan = shard.shard_plan_junctions(...), row_ptr = col = None): the rank clusters its own rows
-    [ext_lo, ext_hi) itself, as in quant_compare_sharded.
+    [ext_lo, ext_hi) itself, as in quant_compare_sharded.  overlap_groups: column groups of the exchange that takes the
+    corrected values home (device engines; default: by the width of a rank's column range, 1 on one rank).
     Returns dict(p=[k, pairs] for this rank's own rows, own=(lo, hi), plan=...).
     """
     if correction not in ("pairwise", "all", "none"):
@@ -614,7 +660,7 @@ def pairwise_sharded(engine, comm, counts_ext, row_ptr, col, correction="pairwis
             raise ValueError("junctions_ext must be in output row order")
     if dev:
         p = _pairwise_dev(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction, test,
-                          junctions=junctions_ext if k else None)
+                          junctions=junctions_ext if k else None, overlap_groups=overlap_groups)
     else:
         p = _pairwise_host(engine, comm, ext, rp, cl, lo - elo, k, plan, n, pairs, correction, test)
     return dict(p=p, own=(lo, hi), plan=plan)

@@ -341,6 +341,16 @@ class Context:
         n, cols = d_p.shape
         check(self.lib.sdice_bh_columns_dev(self.h, n, cols, d_p.ptr), "sdice_bh_columns_dev")
 
+    def bh_columns_pitched_dev(self, d_p, n, cols, pitch):
+        """BH down the columns of rows x cols values whose rows are `pitch` elements apart (a column range of a wider table)"""
+        check(self.lib.sdice_bh_columns_pitched_dev(self.h, int(n), int(cols), int(pitch), d_p.ptr), "sdice_bh_columns_pitched_dev")
+
+    def comm_fork(self):
+        check(self.lib.sdice_comm_fork(self.h), "sdice_comm_fork")
+
+    def comm_join(self):
+        check(self.lib.sdice_comm_join(self.h), "sdice_comm_join")
+
     def bh_masked_dev(self, d_p, d_tested, d_q):
         """BH over the present entries (tested != 0, or p >= 0 when d_tested is None); absent -> 0"""
         check(self.lib.sdice_bh_masked_dev(self.h, int(np.prod(d_p.shape)), d_p.ptr,

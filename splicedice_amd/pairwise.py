@@ -90,11 +90,15 @@ def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header,
     (config 4: 200 000 x 19 900 doubles = 32 GB; the reference holds it in host memory,
     pairwise_fisher.py:123-193), then streamed to the output table in row slabs: device -> host ->
     formatter -> file, so host memory stays bounded by SLAB_BYTES whatever the table size."""
+    from . import _stages
     n, s = counts.shape
     pairs = s * (s - 1) // 2
-    d_counts = ctx.to_device(counts, np.int32)
-    d_rp = ctx.to_device(row_ptr, np.int64)
-    d_col = ctx.to_device(col if col.size else np.zeros(1, np.int32), np.int32)
+    with _stages.stage("h2d"):
+        d_counts = ctx.to_device(counts, np.int32)
+        d_rp = ctx.to_device(row_ptr, np.int64)
+        d_col = ctx.to_device(col if col.size else np.zeros(1, np.int32), np.int32)
+    t_kernels = _stages.stage("kernels")
+    t_kernels.__enter__()
     if excl is None:
         d_excl = ctx.empty((n, s), np.int64)
         ctx.ps_dev(d_counts, d_rp, d_col, d_excl, None)
@@ -122,11 +126,15 @@ def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header,
         d_p = d_q
     elif correction == "pairwise":
         ctx.bh_columns_dev(d_p)
+    ctx.sync()
+    t_kernels.__exit__(None, None, None)
     slab = max(1, SLAB_BYTES // (pairs * 8))
     for r0 in range(0, n, slab):
         k = min(slab, n - r0)
-        textio.write_table(path, header if r0 == 0 else "", events[r0:r0 + k], d_p.offset(r0 * pairs, (k, pairs)).to_host(),
-                           "repr", append=r0 > 0)
+        with _stages.stage("d2h"):
+            host = d_p.offset(r0 * pairs, (k, pairs)).to_host()
+        with _stages.stage("format+write"):
+            textio.write_table(path, header if r0 == 0 else "", events[r0:r0 + k], host, "repr", append=r0 > 0)
     d_p.free()
 
 
@@ -153,9 +161,12 @@ def run_with(args, ctx=None):
     else:
         filter_list = None
 
-    samples, events, counts = get_event_counts(args.inclusionSPLICEDICE, filter_list)
+    from . import _stages
+    with _stages.stage("parse"):
+        samples, events, counts = get_event_counts(args.inclusionSPLICEDICE, filter_list)
     print("Counts loaded from", args.inclusionSPLICEDICE, "...")
-    clusters = get_clusters(args.clusters)
+    with _stages.stage("parse"):
+        clusters = get_clusters(args.clusters)
     print("Clusters loaded from", args.clusters, "...")
     pairs = [(i, j) for i in range(len(samples) - 1) for j in range(i + 1, len(samples))]
     columns = [f"{samples[a]}_{samples[b]}" for a, b in pairs]

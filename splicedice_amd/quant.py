@@ -14,7 +14,7 @@ from time import time
 
 import numpy as np
 
-from . import juncio, textio
+from . import _stages, juncio, textio
 from .engine import Context
 
 
@@ -101,11 +101,13 @@ class Quant:
         print(f"Getting all junctions from {len(self.manifest)} files...")
         # one multithreaded pass per file (csrc/juncio.cpp) instead of the reference's two Python
         # passes; get_all_junctions / get_junction_counts below state the same rules in Python
-        chrom_names, junc, parsed = juncio.ingest(self.manifest, self.args, self.ctx)
+        with _stages.stage("parse"):
+            chrom_names, junc, parsed = juncio.ingest(self.manifest, self.args, self.ctx)
         print("\tDone", timer.check())
 
         print(f"Finding clusters from {junc[0].size} junctions...")
-        row_of, self.row_ptr, self.col = self.ctx.cluster(*junc)
+        with _stages.stage("cluster"):
+            row_of, self.row_ptr, self.col = self.ctx.cluster(*junc)
         rows = [np.empty_like(a) for a in junc]
         for dst, src in zip(rows, junc):
             dst[row_of] = src                                  # row order (SPLICEDICE.py:96)
@@ -130,20 +132,24 @@ class Quant:
 
         print("Writing cluster file...")
         if L.root:
-            self.write_clusters()
+            with _stages.stage("format+write"):
+                self.write_clusters()
         print("\tDone", timer.check())
 
         print("Writing junction bed file...")
         if L.root:
-            self.write_junction_bed()
+            with _stages.stage("format+write"):
+                self.write_junction_bed()
         print("\tDone", timer.check())
 
         print("Gathering junction counts...")
-        self.counts, self.low = juncio.gather_counts(self.manifest, parsed, self.rows, self.args)
+        with _stages.stage("parse"):
+            self.counts, self.low = juncio.gather_counts(self.manifest, parsed, self.rows, self.args)
         print("\tDone", timer.check())
 
         print("Writing inclusion counts...")
-        self.write_inclusions()
+        with _stages.stage("format+write"):
+            self.write_inclusions()
         print("\tDone", timer.check())
 
         print("Calculating PS values...")
@@ -155,6 +161,23 @@ class Quant:
             self.psi = self.ctx.ps(np.ascontiguousarray(self.counts[elo:ehi]), rp, cl)[lo - elo: hi - elo] \
                 if hi > lo else np.zeros((0, s), np.float32)
             low = self.low[(self.low // s >= lo) & (self.low // s < hi)] - lo * s if self.low.size else self.low
+        elif hasattr(self.ctx, "ps_dev"):
+            # the HIP engine, stage by stage (the host entry point sdice_ps does the same three steps in one call)
+            ctx = self.ctx
+            with _stages.stage("h2d"):
+                d_counts = ctx.to_device(self.counts, np.int32)
+                d_rp = ctx.to_device(self.row_ptr, np.int64)
+                d_col = ctx.to_device(self.col if self.col.size else np.zeros(1, np.int32), np.int32)
+                d_ps = ctx.empty(self.counts.shape, np.float32)
+            with _stages.stage("kernels"):
+                if self.counts.size:
+                    ctx.ps_dev(d_counts, d_rp, d_col, None, d_ps)
+                ctx.sync()
+            with _stages.stage("d2h"):
+                self.psi = d_ps.to_host()
+            for a in (d_counts, d_rp, d_col, d_ps):
+                a.free()
+            low = self.low
         else:
             self.psi = self.ctx.ps(self.counts, self.row_ptr, self.col)
             low = self.low
@@ -163,7 +186,8 @@ class Quant:
         print("\tDone", timer.check())
 
         print("Writing PS values...")
-        self.write_all_psi()
+        with _stages.stage("format+write"):
+            self.write_all_psi()
         print("\tDone", timer.check())
 
         if self.args.drim:

@@ -447,6 +447,18 @@ def test_annotation_columns_against_reference_table(golden_dir, tmp_path, gtf, t
     assert got[1:] == [f"{nm}\t{str(np.float64(v))}{s}" for nm, v, s in zip(names, x, sfx)]
 
 
+def test_rank_over_m_by_reciprocal(tmp_path):
+    """bh_cols.hip raw_bits_inv(): the ecdf factor rank / m of statsmodels' fdr_bh by a reciprocal and one exact residual
+    step instead of an IEEE division -- equal to the division for every rank of 321 column lengths up to 2^18
+    (tests/host_c/rank_over_m.c, compiled here with gcc; 405 M cases with 3000 random lengths were run once by hand)"""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_c", "rank_over_m.c")
+    exe = str(tmp_path / "rank_over_m")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    r = subprocess.run([exe, "300"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("bad 0"), r.stdout
+
+
 def test_ps_of_key_formula_reproduces_the_table():
     """ranksum.hip ps_of_key(): q = k * 0.001f; q = fma(fma(-q, 1000, k), 0.001f, q) must equal float32(k / 1000.0)
     (the '.3f' text read back as float32, compareSampleSets.py:202) for every k = 0..1000 -- exact rational

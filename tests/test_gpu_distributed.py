@@ -94,7 +94,8 @@ def test_own_range_clustering_equals_replicated_clustering(ctx, kw):
             assert np.array_equal(v, got["junctions"][k], equal_nan=True), k
         pw = {}
         for mode in ("csr", "junctions"):
-            sh = distributed.PairwiseShard(ctx, distributed.SingleComm(), n, 8, [part], "pairwise", "fisher")
+            # (correction "none": the raw p-values of the shard's rows -- column BH needs every rank's rows)
+            sh = distributed.PairwiseShard(ctx, distributed.SingleComm(), n, 8, [part], "none", "fisher")
             try:
                 e8 = np.ascontiguousarray(ext[:, :8])
                 sh.load(e8, rp, cl) if mode == "csr" else sh.load(e8, junctions=jext)
@@ -142,5 +143,11 @@ def test_sharded_pairwise_on_engine(ctx):
         assert np.array_equal(out2["p"], out["p"])
         blocks = np.arange(12, dtype=np.float64).reshape(1, 3, 4)
         assert np.array_equal(comm.alltoall(blocks), blocks)
+        # the way home in column groups on the context's second stream (sdice_comm_fork / _join), pitched column BH per group
+        for groups in (3, 7):
+            outg = distributed.pairwise_sharded(c, comm, counts, row_ptr, col, "pairwise", overlap_groups=groups)
+            assert np.array_equal(outg["p"], out["p"]), groups
+        outg = distributed.pairwise_sharded(ctx, distributed.SingleComm(), counts, row_ptr, col, "pairwise", overlap_groups=4)
+        assert np.array_equal(outg["p"], out["p"])
         out3 = distributed.pairwise_sharded(c, comm, counts, row_ptr, col, "all")
         np.testing.assert_allclose(out3["p"], O.bh_fdr(full_raw.reshape(-1)).reshape(full_raw.shape), rtol=1e-12, atol=0)

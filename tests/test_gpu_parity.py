@@ -213,6 +213,42 @@ def test_cluster_async_error_survives_a_later_chain(ctx):
     assert nnz == want[2].size and np.array_equal(d_row_ptr2.to_host(), want[1])
 
 
+def test_cluster_lookback_tile_loop_and_give_up(ctx):
+    """The neighbour kernel's workgroups walk their tiles in increasing order (a grid no larger than what the device
+    holds at once: the look-back's forward progress): a grid of 3 / 8 workgroups over ~118 tiles gives the lists of the
+    one-workgroup-per-tile launch.  And a look-back that gives up (forced: cluster.ablate = 256) is not silent: the
+    synchronous call falls back to the generic chain and still returns the reference's lists, the asynchronous one
+    reports it at the next sync."""
+    from splicedice_amd.engine import SdiceError
+    n = 60_000
+    cr, left, right, strand = synth.make_junctions(n, 61)
+    want = ctx.cluster(cr, left, right, strand)
+    d = [ctx.to_device(x) for x in (cr, left, right, strand)]
+    d_row_of, d_row_ptr = ctx.empty(n, np.int32), ctx.empty(n + 1, np.int64)
+    try:
+        for grid in (3, 8):
+            ctx.set_param("cluster.nb_grid", grid)
+            got = ctx.cluster(cr, left, right, strand)
+            assert all(np.array_equal(g, w) for g, w in zip(got, want)), grid
+            d_row_ptr.zero()
+            d_col, _ = ctx.cluster_dev(*d, d_row_of, d_row_ptr, sync=False)          # asynchronous chain, same grid
+            nnz, _ = ctx.cluster_status()
+            assert nnz == want[2].size and np.array_equal(d_row_ptr.to_host(), want[1])
+            assert np.array_equal(d_col.offset(0, (nnz,)).to_host(), want[2])
+        ctx.set_param("cluster.nb_grid", 0)
+        ctx.set_param("cluster.ablate", 256)
+        got = ctx.cluster(cr, left, right, strand)                                    # synchronous: generic path takes over
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+        ctx.cluster_dev(*d, d_row_of, d_row_ptr, sync=False)
+        with pytest.raises(SdiceError, match="look-back"):
+            ctx.sync()
+    finally:
+        ctx.set_param("cluster.nb_grid", 0)
+        ctx.set_param("cluster.ablate", 0)
+    got = ctx.cluster(cr, left, right, strand)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
 def test_cluster_list_size_is_bounded(ctx):
     """A clustering whose neighbour lists exceed the cap ends in a clean SDICE_ERR_NOMEM that names the size, before
     anything of that size is allocated on the device or the host (the reference degrades gracefully with Python lists,
@@ -788,13 +824,19 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
         ctx.bh_columns_dev(d)
         fast = d.to_host()
         assert np.array_equal(generic, fast, equal_nan=True)
-        ctx.set_param("bh.keys", 8)                                           # eight keys per lane in the main bucket kernel
-        ctx.set_param("bh.mean", 400)
+        for wg, mean in ((256, 100), (256, 900), (512, 0), (1024, 0), (256, 3000)):     # threads of a bucket workgroup (4 values
+            ctx.set_param("bh.wg", wg)                                        # each), mean bucket (0: half its capacity); 900 and
+            ctx.set_param("bh.mean", mean)                                    # 3000 fill the second kernel's list
+            d = ctx.to_device(p)
+            ctx.bh_columns_dev(d)
+            assert np.array_equal(generic, d.to_host(), equal_nan=True), (wg, mean)
+        ctx.set_param("bh.wg", 256)
+        ctx.set_param("bh.mean", 0)
+        ctx.set_param("bh.fused_count", 0)                                    # transpose and count as two kernels
         d = ctx.to_device(p)
         ctx.bh_columns_dev(d)
         assert np.array_equal(generic, d.to_host(), equal_nan=True)
-        ctx.set_param("bh.keys", 4)
-        ctx.set_param("bh.mean", 200)
+        ctx.set_param("bh.fused_count", 1)
         if n > 2000:
             ctx.set_param("bh.reg_cap", 64)                                   # most buckets through the in-HBM path
             d = ctx.to_device(p)
@@ -802,9 +844,10 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
             assert np.array_equal(generic, d.to_host(), equal_nan=True)
     finally:
         ctx.set_param("bh.columns_path", 0)
-        ctx.set_param("bh.reg_cap", 1024)
-        ctx.set_param("bh.keys", 4)
-        ctx.set_param("bh.mean", 200)
+        ctx.set_param("bh.reg_cap", 2048)
+        ctx.set_param("bh.mean", 0)
+        ctx.set_param("bh.wg", 256)
+        ctx.set_param("bh.fused_count", 1)
     ok = ~np.isnan(p).any(axis=0)
     np.testing.assert_allclose(fast[:, ok], O.bh_columns(p[:, ok]), rtol=1e-14, atol=0)
 

@@ -25,5 +25,5 @@ for rep in range(3):
             ctx.copy2d_dev(d.ptr, cols * 8, d_src.ptr, cols * 8, cols * 8, n)
             ctx.sync(); ctx.timer_start(); ctx.bh_columns_dev(d); ms.append(ctx.timer_stop())
         for k, v in kv:
-            ctx.set_param(k, {"bh.reg_cap": 1024, "bh.mean": 200, "bh.spb": 8, "bh.keys": 4}.get(k, 0))
+            ctx.set_param(k, {"bh.reg_cap": 2048, "bh.mean": 0, "bh.wg": 256, "bh.spb": 8, "bh.fused_count": 1, "bh.rows_per_block": 2048, "bh.finish_cols": 16}.get(k, 0))
         print(f"rep {rep} [{c}] {min(ms[1:]):.3f} ms  ({n * cols / min(ms[1:]) / 1e6:.2f} G values/s)", flush=True)
