@@ -3,6 +3,8 @@
 // and keeps those that contain the event's start or stop.  Here: the same scan, threaded, over flat arrays;
 // the result is a CSR of interval indices in the reference's order (the dict order of the intervals).
 #include "sdice.h"
+
+int sd_default_threads();   // textio.cpp: hardware threads capped by the cgroup's CPU quota
 #include <algorithm>
 #include <cstdint>
 #include <exception>
@@ -18,7 +20,7 @@ namespace {
 // the caller's thread, where the extern "C" function-try-block turns it into SDICE_ERR_*.
 template <class F>
 void for_blocks(int64_t n, int threads, F f) {
-    int used = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int used = threads > 0 ? threads : sd_default_threads();
     if (used < 1) used = 1;
     if (used > 64) used = 64;
     if (n < 4096) used = 1;

@@ -147,8 +147,11 @@ __global__ void __launch_bounds__(256) bhs_sample_kernel(BhsArgs a) {
 // doubles per column out.  COUNT: every value is classified against its column's splitters (LDS) on the way; the
 // histogram stays in LDS until the workgroup is through its rows.
 constexpr int TC_COLS = 16, TC_ROWS = 128, TC_T = 256;
+// 1-D grid, workgroups dealt round-robin over the 8 XCDs: XCD x takes the strips [x spx, (x + 1) spx), neighbouring
+// strips of one row block back to back -- a 128-byte row piece starts wherever (row x pitch) mod 128 puts it, so every
+// piece shares its first and last line with the neighbouring strips, and those lines should meet in ONE L2.
 template <bool COUNT>
-__global__ void __launch_bounds__(TC_T) bhs_transpose_kernel(BhsArgs a, int rows_per_block) {
+__global__ void __launch_bounds__(TC_T) bhs_transpose_kernel(BhsArgs a, int rows_per_block, int strips_per_xcd) {
     extern __shared__ uint64_t smem_tc[];
     __shared__ double tile[TC_COLS][TC_ROWS + 1];
     const int ns = a.B - 1;
@@ -157,9 +160,11 @@ __global__ void __launch_bounds__(TC_T) bhs_transpose_kernel(BhsArgs a, int rows
     unsigned* hist = reinterpret_cast<unsigned*>(si + (COUNT ? TC_COLS * ns : 0));  // [TC_COLS][B]
 
     const int tid = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * TC_COLS;
+    const int64_t kb = (int64_t)(blockIdx.x >> 3);
+    const int64_t c0 = ((int64_t)(blockIdx.x & 7) * strips_per_xcd + kb % strips_per_xcd) * TC_COLS;
+    if (c0 >= a.segs) return;
     const int ncol = (int)min((int64_t)TC_COLS, (int64_t)a.segs - c0);
-    const int64_t rb0 = (int64_t)blockIdx.y * rows_per_block, rb1 = min(a.m, rb0 + rows_per_block);
+    const int64_t rb0 = (kb / strips_per_xcd) * rows_per_block, rb1 = min(a.m, rb0 + rows_per_block);
     if (COUNT) {
         for (int i = tid; i < ncol * ns; i += TC_T) {
             const int c = i / ns, b = i - c * ns;
@@ -1259,7 +1264,10 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm,
     const int64_t strips = sd_ceil_div(segs, (int64_t)TC_COLS);
     SD_ARG(strips < ((int64_t)1 << 31), "bh: too many columns");
     const int rows_per_block = (int)std::max<int64_t>(TC_ROWS, std::min<int64_t>(ctx->param("bh.rows_per_block", 2048), m));
-    const dim3 tgrid((unsigned)strips, (unsigned)sd_ceil_div(m, (int64_t)rows_per_block));
+    const int strips_per_xcd = (int)sd_ceil_div(strips, (int64_t)8);
+    const int64_t tblocks = (int64_t)strips_per_xcd * 8 * sd_ceil_div(m, (int64_t)rows_per_block);
+    SD_ARG(tblocks < ((int64_t)1 << 31), "bh: too many tiles");
+    const dim3 tgrid((unsigned)tblocks);
     if (B > 1) {
         SD_HIP(hipMemsetAsync(a.gcount, 0, sb * 4, ctx->stream));
         const size_t lds_s = (size_t)a.S2 * 12;
@@ -1274,15 +1282,15 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm,
         // transpose runs alone and the tiles of the scatter kernel count first
         const size_t lds_tc = (size_t)TC_COLS * ((size_t)(B - 1) * 12 + (size_t)B * 4);
         if (lds_tc <= 48 * 1024 && ctx->param("bh.fused_count", 1)) {
-            SD_LAUNCH(ctx, "bhs_transpose_count_kernel", (bhs_transpose_kernel<true>), tgrid, dim3(TC_T), lds_tc, a, rows_per_block);
+            SD_LAUNCH(ctx, "bhs_transpose_count_kernel", (bhs_transpose_kernel<true>), tgrid, dim3(TC_T), lds_tc, a, rows_per_block, strips_per_xcd);
         } else {
-            SD_LAUNCH(ctx, "bhs_transpose_kernel", (bhs_transpose_kernel<false>), tgrid, dim3(TC_T), 0, a, rows_per_block);
+            SD_LAUNCH(ctx, "bhs_transpose_kernel", (bhs_transpose_kernel<false>), tgrid, dim3(TC_T), 0, a, rows_per_block, strips_per_xcd);
             SD_LAUNCH(ctx, "bhs_count_kernel", (bhs_tile_kernel<false>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
         }
         SD_LAUNCH(ctx, "bhs_scan_kernel", bhs_scan_kernel, dim3((unsigned)segs), dim3(256), 0, a);
         SD_LAUNCH(ctx, "bhs_scatter_kernel", (bhs_tile_kernel<true>), dim3((unsigned)tile_blocks), dim3(TILE_T), lds_t, a, (int)tiles);
     } else {
-        SD_LAUNCH(ctx, "bhs_transpose_kernel", (bhs_transpose_kernel<false>), tgrid, dim3(TC_T), 0, a, rows_per_block);
+        SD_LAUNCH(ctx, "bhs_transpose_kernel", (bhs_transpose_kernel<false>), tgrid, dim3(TC_T), 0, a, rows_per_block, strips_per_xcd);
     }
     const int64_t n_buckets = segs * B;
     const int64_t bucket_blocks = sd_ceil_div(segs, (int64_t)8) * 8 * B;

@@ -28,6 +28,8 @@
 #include <unistd.h>
 #include "sdice.h"
 
+int sd_default_threads();   // textio.cpp: hardware threads capped by the cgroup's CPU quota
+
 void sdice_set_error(const char* fmt, ...);
 
 struct sdice_juncfile {
@@ -189,7 +191,7 @@ extern "C" int sdice_junc_read(sdice_juncfile* t, int32_t min_length, int32_t ma
         }
         chrom_off[t->chroms.size()] = off;
     }
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : sd_default_threads();
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
     if (t->n < 8192) nthreads = 1;
@@ -308,7 +310,7 @@ extern "C" int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const
                                  const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
                                  const int8_t* q_strand, int32_t* row_out, int threads) try {
     if (n_rows < 0 || n_q < 0 || (n_q > 0 && !row_out)) { sdice_set_error("sdice_junc_lookup: bad arguments"); return SDICE_ERR_ARG; }
-    int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : sd_default_threads();
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
     if (n_q < 8192) nthreads = 1;

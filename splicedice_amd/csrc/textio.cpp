@@ -175,7 +175,8 @@ inline char* repr_to(char* o, T x) {
 
 // worker threads by default: the hardware's, capped by the cgroup's CPU quota (a one-GPU box of the pool reports 256 hardware
 // threads and grants 16 cores: 64 formatter threads on 16 cores ran slower than 16)
-inline int default_threads() {
+}  // namespace
+int sd_default_threads() {
     static const int cached = [] {
         int n = (int)std::thread::hardware_concurrency();
         if (n < 1) n = 1;
@@ -193,6 +194,8 @@ inline int default_threads() {
     }();
     return cached;
 }
+namespace {
+inline int default_threads() { return sd_default_threads(); }
 
 // An exception inside a worker (std::bad_alloc from a growing row buffer) or from a thread that cannot be started
 // must not reach std::terminate: workers catch into `err`, every started thread is joined, the first exception is

@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 summaries for one round (run on the GPU box through gpurun from the repo root):
-#   tools/profile_round.sh r03            (every workload)
-#   tools/profile_round.sh r03 compare    (one workload's trace + traffic passes only; summarise locally afterwards)
+#   tools/profile_round.sh r04            (every workload)
+#   tools/profile_round.sh r04 compare    (one workload's trace + traffic passes only; summarise locally afterwards)
 # kernel-trace/stats and the PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass;
 # counters are never combined with the trace domains).  The program itself follows `--` (python3 bench.py).
 # Workloads: quant = the headline (2M x 500), quantc2 = BASELINE config 2 (1M x 100), compare, pairwise, e2e.
-R=${1:-r03}
+R=${1:-r04}
 ONLY=${2:-}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
