@@ -765,16 +765,20 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     const int n = (int)a.n;
     const int n_tiles = (n + T - 1) / T;
     const bool failed_chain = (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW | ST_DUP)) != 0;
-    // a workgroup takes its tiles in increasing order (see lookback_exclusive)
+    // a workgroup takes its tiles in increasing order (see lookback_exclusive): its first tile is its id, every further
+    // one comes from a counter (tickets gridDim.x, gridDim.x + 1, ...: a workgroup that drew cheap tiles takes more of
+    // them, as the dispatcher would have arranged; a fixed stride cost 30 % of the kernel at 2 M junctions)
+    __shared__ int s_tile;
+    unsigned long long* ticket = a.tile_state + n_tiles;
 #pragma nounroll
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    if (tile != (int)blockIdx.x) __syncthreads();          // (the previous tile's readers are done with the LDS)
+    for (int tile = blockIdx.x; tile < n_tiles;) {
     const int t0 = tile * T;
     const int nr = min(T, n - t0);
     if (failed_chain) {
         // failed chain: leave an all-zero row_ptr (every list empty) so that a dependent launch stays in bounds
         if (t < nr) { a.row_ptr[t0 + t] = 0; if ((t & 15) == 0) a.blkneed[(t0 + t) >> 4] = 0; }
         if (t0 + t == 0) a.row_ptr[n] = 0;
+        tile += gridDim.x;                                  // (nothing to balance)
         continue;
     }
     if (t == 0) s_misc[2] = 0;
@@ -988,6 +992,10 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
         walk_back_global(a, r - 1, c, l, st, maxlen, put);
         walk_fwd_global(a, r + 1, n, c, rgt, st, put);
     }
+    // next tile (the barrier also says: this tile's readers are done with the LDS)
+    if (t == 0) s_tile = (int)gridDim.x + (int)atomicAdd(ticket, 1ull);
+    __syncthreads();
+    tile = s_tile;
     }   // tile loop
 }
 
@@ -1038,7 +1046,7 @@ int fast_plan(sdice_ctx* ctx, int64_t n, const int32_t* d_chrom, const int32_t* 
         SD_HIP(hipMemsetAsync(ctx->cluster_sb, 0, (size_t)SB_ALLOC_WORDS * 8, ctx->stream));
     }
     // zero region: [tile states] (needed by every neighbour run) then [cursor | rank | bmax64]
-    const size_t zk4 = (size_t)pl.n_tiles * 8;
+    const size_t zk4 = ((size_t)pl.n_tiles + 2) * 8;      // (+ the ticket counter of the tile loop behind the tile states)
     const size_t n_cd = (size_t)(a.S + 255) / 256 + 4;
     const size_t zrest = (size_t)a.B * 4 + (size_t)(a.S + 4) * 4 + nb64 * 4 + n_cd * 4;     // cursor | rank | bmax64 | col_done
     const size_t slots_bytes = (size_t)a.B * (size_t)a.slot_cap * 16;

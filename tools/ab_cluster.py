@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from splicedice_amd import synth
 from splicedice_amd.engine import Context
-DEFAULTS = {"cluster.bucket_mean": 2048, "cluster.spb": 0, "cluster.sample_sort": 1}
+DEFAULTS = {"cluster.bucket_mean": 2048, "cluster.spb": 0, "cluster.sample_sort": 1, "cluster.nb_grid": 0}
 n = int(sys.argv[1])
 cfgs = sys.argv[2:] or [""]
 ctx = Context(0)
