@@ -150,19 +150,22 @@ def compare(matrix, g1_idx, g2_idx, ctx):
 
 
 def compare_sharded(matrix, g1_idx, g2_idx, ctx, L):
-    """compare() with the table rows cut into one block per rank (rows are independent here): every rank
-    tests its block, the per-row statistics are all-gathered (padded to equal length), rank 0 corrects."""
+    """compare() with the table rows cut into one block per rank (rows are independent here): every rank tests its
+    block, the per-row statistics cross the ranks as ONE packed block in ONE all-gather (distributed.stat_layout, padded to
+    the longest block), rank 0 corrects."""
+    from . import distributed
     n = matrix.shape[0]
     lo, hi = L.row_block(n)
-    maxk = max(max(L.row_block(n, r)[1] - L.row_block(n, r)[0] for r in range(L.world)), 1)
+    blocks = [L.row_block(n, r) for r in range(L.world)]
+    maxk = max(max(b - a for a, b in blocks), 1)
     res = ctx.ranksum(np.ascontiguousarray(matrix[lo:hi]), g1_idx, g2_idx)
-    comm = L.comm(ctx)
-    full = {}
-    for k in ("tested", "p", "med1", "med2", "mean1", "mean2", "delta"):
-        pad = np.zeros(maxk, dtype=res[k].dtype)
-        pad[: hi - lo] = res[k]
-        g = comm.allgather(pad)
-        full[k] = np.concatenate([g[r * maxk: r * maxk + L.row_block(n, r)[1] - L.row_block(n, r)[0]] for r in range(L.world)])
+    stats = {k: np.zeros(maxk, dt) for k, dt in zip(distributed.STAT_NAMES, distributed._STAT_DTYPES)}
+    for k in distributed.STAT_NAMES:
+        stats[k][: hi - lo] = res[k]
+    gathered = L.comm(ctx).allgather(distributed.pack_stats_host(stats, maxk))
+    host = distributed.unpack_stats_host(gathered, maxk, L.world)
+    full = {k: np.concatenate([host[k][r * maxk: r * maxk + b - a] for r, (a, b) in enumerate(blocks)])
+            for k in ("tested", "p", "med1", "med2", "mean1", "mean2", "delta")}
     keep = np.flatnonzero(full["tested"])
     out = {k: full[k][keep] for k in ("p", "med1", "med2", "mean1", "mean2", "delta")}
     out["corrected"] = ctx.bh(out["p"]) if (keep.size and L.root) else np.zeros(keep.size)

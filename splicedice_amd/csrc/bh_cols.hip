@@ -487,7 +487,19 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
         for (int w = 1; w < NW; ++w) { lo = wred[w] < lo ? wred[w] : lo; hi = wred[NW + w] > hi ? wred[NW + w] : hi; }
     }
     const uint64_t range = hi - lo;
-    const int bits = range ? 64 - __builtin_clzll(range) : 0;
+    if (range == 0ull) {
+        // (block-uniform) a bucket of ONE repeated value -- Fisher's p = 1 and the other discrete levels fill whole buckets:
+        // nothing to rank (any order is a valid one), p * m / rank falls with the rank, so every member's value inside the
+        // bucket is that of the LAST rank.  No LDS, no atomics (1 024 atomic increments of ONE counter are what such a
+        // bucket would cost in the counting sort).
+        const uint64_t last = n_b > 0 ? raw_bits(lo, (int64_t)r.start + n_b, a.m) : ~0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (ok[k]) r.ks[k * T + tid] = last;
+        if (tid == 0) *r.bm = last;
+        return;
+    }
+    const int bits = 64 - __builtin_clzll(range);
     const int sh = __builtin_amdgcn_readfirstlane(bits > LOGB ? bits - LOGB : 0);
     __syncthreads();
     int bin[K];

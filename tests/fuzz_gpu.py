@@ -269,9 +269,22 @@ def gen_bh(ctx, rng):
     if n * cols > 1_500_000:
         cols = max(1, 1_500_000 // n)
     p = rng.random((n, cols)) ** float(rng.choice([1, 3, 20]))
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 10))
     if kind == 1:
         p[rng.random((n, cols)) < 0.6] = 1.0
+    elif kind == 6:                                   # a dense cluster of DISTINCT values inside a wide range: one bin of the
+        m = rng.random((n, cols)) < 0.5               # bucket's counting sort holds many different keys
+        p[m] = 0.3 + rng.integers(0, 4000, size=int(m.sum())) * 2.0 ** -52
+    elif kind == 7:                                   # p-values over hundreds of binades (key space is logarithmic there)
+        p[:] = 10.0 ** -(rng.random((n, cols)) * 300)
+    elif kind == 8:                                   # NaN, inf, negative values and zeros among ordinary ones
+        q = rng.random((n, cols))
+        p[q < 0.02] = np.nan
+        p[(q >= 0.02) & (q < 0.03)] = np.inf
+        p[(q >= 0.03) & (q < 0.05)] = -p[(q >= 0.03) & (q < 0.05)]
+        p[(q >= 0.05) & (q < 0.08)] = 0.0
+    elif kind == 9:                                   # two values only, one of them rare
+        p[:] = np.where(rng.random((n, cols)) < 0.01, 0.25, 1.0)
     elif kind == 2:
         p[:] = rng.choice([1.0, 0.5, 0.0286, 0.2, 1e-5], size=(n, cols))
     elif kind == 3:
@@ -280,15 +293,20 @@ def gen_bh(ctx, rng):
         p[:] = 0.5 + rng.integers(0, 9, size=(n, cols)) * 2.0 ** -53
     elif kind == 5:
         p[:] = np.sort(p, axis=0)[::-1] if rng.random() < 0.5 else np.sort(p, axis=0)
+    wg, mean, fused = int(rng.choice([256, 256, 512, 1024])), int(rng.choice([0, 0, 100, 700, 2500])), int(rng.integers(0, 2))
     try:
         ctx.set_param("bh.columns_path", 1)
         d = ctx.to_device(p); ctx.bh_columns_dev(d); generic = d.to_host()
         ctx.set_param("bh.columns_path", 2)
+        ctx.set_param("bh.wg", wg); ctx.set_param("bh.mean", mean); ctx.set_param("bh.fused_count", fused)
         d = ctx.to_device(p); ctx.bh_columns_dev(d); fast = d.to_host()
     finally:
         ctx.set_param("bh.columns_path", 0)
-    if not np.array_equal(generic, fast):
-        return f"bh columns: sample-sort path != generic path (n={n} cols={cols} kind={kind})"
+        ctx.set_param("bh.wg", 256); ctx.set_param("bh.mean", 0); ctx.set_param("bh.fused_count", 1)
+    if not np.array_equal(generic, fast, equal_nan=True):
+        return f"bh columns: sample-sort path != generic path (n={n} cols={cols} kind={kind} wg={wg} mean={mean} fused={fused})"
+    if kind == 8:
+        return None                                   # (the oracle's definition is for proper p-values)
     if n <= 5000 and not np.allclose(fast, O.bh_columns(p), rtol=1e-14, atol=0):
         return f"bh columns differs from the oracle (n={n} cols={cols} kind={kind})"
     v = p[:, 0].copy()

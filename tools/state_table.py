@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Print the section-0 table of DESIGN.md from profiles/<round>_*: kernel, workload, ms (rocprofv3 average), fraction of
-8 TB/s, PMC traffic / algorithmic bytes.   tools/state_table.py r03"""
+8 TB/s, PMC traffic / algorithmic bytes.   tools/state_table.py r04"""
 import csv, json, os, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 traffic = {(e["workload"], e["n"], e["s"]): e for e in json.load(open(os.path.join(P, "pmc_traffic.json")))}
 ROWS = [("quant", "quant", 2_000_000, 500, "ps_tile_v3", lambda n, s: 8.0 * n * s, "quant 2 M x 500"),
