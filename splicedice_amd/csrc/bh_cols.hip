@@ -451,7 +451,7 @@ __device__ __forceinline__ BucketRef bucket_ref(const BhsArgs& a, int64_t g) {
 // them per column -- long runs in the scatter, few search steps everywhere, a small sample to sort -- and a workgroup
 // ranks a large bucket at K = 4 values per thread (48 VGPRs) where one wave per bucket would need 16 and more per lane.
 // Workgroup barriers between the phases; the resolving loop's trip count stays per WAVE (the largest mixed bin among ITS
-// values).  LDS: L[NS] (8 B) | CNT[2 NS + 4] (4 B) | wred[32] (8 B) | wtot[16] (4 B) = 16 NS + 336 bytes.
+// values).  LDS: L[NS] (8 B) | CNT[2 NS + 4] (4 B) | wred[32] (8 B) | wtot[16] (4 B) | hv[4] (4 B) = 16 NS + 352 bytes.
 template <int T, int K>
 __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef& r, uint64_t* smem) {
     constexpr int NS = T * K, BINS = 2 * NS, NW = T / 64;
@@ -461,6 +461,8 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
     uint64_t* wred = L + NS;                                          // [2 NW]
     unsigned* CNT = reinterpret_cast<unsigned*>(wred + 32);          // [BINS + 4]
     unsigned* wtot = CNT + BINS + 4;                                  // [NW]
+    unsigned* hv = wtot + 16;                                         // [0] a bin beyond HEAVY exists, [1] work-list length
+    constexpr int HEAVY = 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_b = r.n_b;
     uint64_t key[K];
@@ -473,6 +475,7 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
         if (ok[k]) key[k] = r.pd ? key_of(r.pd[p]) : __builtin_nontemporal_load(r.ks + p);
     }
     for (int i = tid; i < BINS + 1; i += T) CNT[i] = 0u;
+    if (tid == 0) { hv[0] = 0u; hv[1] = 0u; }
     uint64_t lo = r.lo, hi = r.hi;
     if (r.end) {                                   // (block-uniform) bounds from the keys
         uint64_t mn = ~0ull, mx = 0ull;
@@ -501,21 +504,37 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
     }
     const int bits = 64 - __builtin_clzll(range);
     const int sh = __builtin_amdgcn_readfirstlane(bits > LOGB ? bits - LOGB : 0);
+    // (block-uniform) A bucket whose bounds lie in different binades -- a column's FIRST bucket reaches from its smallest
+    // p-value, many binades down, to the first splitter -- is badly served by bins that are linear in the key BITS alone:
+    // uniformly distributed values put half the bucket into the top binade, i.e. into 2 of the 2 048 bins, and the
+    // resolving loop below runs once per member of the fullest bin.  Such a bucket takes the MEAN of two monotone maps,
+    // linear in the bits (spreads a tail over many decades) and linear in the value (spreads the uniform part): the mean
+    // of two non-decreasing maps is non-decreasing, which is all the ranking needs.  Keys between two finite
+    // non-negative bounds are finite non-negative doubles, so the value map is monotone over the whole bucket.
+    const bool blend = (hi >> 52) != (lo >> 52) && hi < 0x7ff0000000000000ull;
+    const double plo = __longlong_as_double((long long)lo);
+    const double scale = blend ? (double)(BINS - 1) / (__longlong_as_double((long long)hi) - plo) : 0.0;
     __syncthreads();
     int bin[K];
     unsigned slot[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint64_t d = (key[k] - lo) >> sh;
-        bin[k] = (int)(d < (uint64_t)(BINS - 1) ? d : (uint64_t)(BINS - 1));
+        unsigned bn = (unsigned)(d < (uint64_t)(BINS - 1) ? d : (uint64_t)(BINS - 1));
+        if (blend) {
+            const unsigned bv = (unsigned)((__longlong_as_double((long long)key[k]) - plo) * scale);
+            bn = (bn + (bv < (unsigned)(BINS - 1) ? bv : (unsigned)(BINS - 1))) >> 1;
+        }
+        bin[k] = (int)bn;
         slot[k] = 0u;
         if (ok[k]) slot[k] = atomicAdd(&CNT[bin[k]], 1u);
     }
     __syncthreads();
     {   // exclusive scan over the bins: thread t owns bins [2 K t, 2 K t + 2 K)
-        unsigned c[2 * K], tot = 0;
+        unsigned c[2 * K], tot = 0, cm = 0;
 #pragma unroll
-        for (int j = 0; j < 2 * K; ++j) { c[j] = CNT[tid * 2 * K + j]; tot += c[j]; }
+        for (int j = 0; j < 2 * K; ++j) { c[j] = CNT[tid * 2 * K + j]; tot += c[j]; cm = c[j] > cm ? c[j] : cm; }
+        if (cm > (unsigned)HEAVY) hv[0] = 1u;
         unsigned x = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -528,6 +547,7 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
         if (tid == T - 1) CNT[BINS] = pre;
     }
     __syncthreads();
+    const bool heavy_path = hv[0] != 0u;            // (block-uniform)
     int sb[K], cb[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -546,14 +566,59 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
         if (ok[k] && L[sb[k]] != key[k]) atomicOr(&CNT[bin[k]], 0x80000000u);
     __syncthreads();
     unsigned before[K];
-    int cmax = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const bool mixed = ok[k] && (CNT[bin[k]] & 0x80000000u) != 0u;
         before[k] = mixed ? 0u : slot[k];
         if (!mixed) cb[k] = 0;
-        cmax = cb[k] > cmax ? cb[k] : cmax;
     }
+    // The resolving loop below runs, for a whole wave, once per member of the FULLEST mixed bin among the wave's values.
+    // Where the values crowd inside a bucket (Fisher's p-values just below 1; any spike narrower than a bin) one bin of a
+    // hundred members would hold all four waves for a hundred trips.  The members of mixed bins beyond HEAVY leave the
+    // loop: they go to a work list (over the bin counters, which are dead by now), and every listed value is counted by
+    // FOUR lanes that share its bin's members between them -- the work of a heavy bin is spread over the workgroup
+    // instead of being paid by every wave that holds one of its members.
+    int went[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) went[k] = -1;
+    if (heavy_path) {
+        uint64_t* WL = reinterpret_cast<uint64_t*>(CNT);          // [<= NS] start | count << 16 | slot << 32, then the result
+        __syncthreads();                                           // every read of the bin counters is done
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (cb[k] > HEAVY) {
+                went[k] = (int)atomicAdd(&hv[1], 1u);
+                WL[went[k]] = (uint64_t)(unsigned)sb[k] | ((uint64_t)(unsigned)cb[k] << 16) | ((uint64_t)slot[k] << 32);
+                cb[k] = 0;
+            }
+        }
+        __syncthreads();
+        const int nwl = (int)hv[1];
+        const int q = lane & 3;
+        for (int e0 = wave * 16; e0 < nwl; e0 += NW * 16) {        // (wave-uniform) 16 listed values per wave and round
+            const int e = e0 + (lane >> 2);
+            const uint64_t w = e < nwl ? WL[e] : 0ull;
+            const int s0 = (int)(w & 0xffffu), c = (int)((w >> 16) & 0xffffu);
+            const unsigned sl = (unsigned)(w >> 32);
+            const uint64_t kk = L[s0 + (int)sl];
+            unsigned cnt = 0u;
+            for (int j = q; __ballot(j < c) != 0ull; j += 4) {
+                const bool in = j < c;
+                const uint64_t kj = L[s0 + (in ? j : 0)];
+                count_less96(cnt, in ? kj : ~0ull, in ? (unsigned)j : ~0u, kk, sl);
+            }
+            cnt += __shfl_xor(cnt, 1);
+            cnt += __shfl_xor(cnt, 2);
+            if (e < nwl && q == 0) WL[e] = (uint64_t)cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (went[k] >= 0) before[k] = (unsigned)WL[went[k]];
+    }
+    int cmax = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) cmax = cb[k] > cmax ? cb[k] : cmax;
     for (int i = 0; __ballot(i < cmax) != 0ull; ++i) {
         uint64_t kj[K];
 #pragma unroll
@@ -612,7 +677,7 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
     for (int k = 0; k < K; ++k)
         if (ok[k]) r.ks[k * T + tid] = L[rank[k]];        // in place: the slot the key came from
 }
-template <int T, int K> constexpr size_t bucket_wg_lds() { return (size_t)T * K * 16 + 16 + 32 * 8 + 16 * 4; }
+template <int T, int K> constexpr size_t bucket_wg_lds() { return (size_t)T * K * 16 + 16 + 32 * 8 + 16 * 4 + 16; }
 
 // one workgroup of T threads per bucket of up to 4 T values; larger ones go to the work list of the second kernel.
 // Workgroups are dealt round-robin over the 8 XCDs: all buckets of one column go to workgroups of ONE XCD (column mod

@@ -23,7 +23,7 @@ if sys.argv[2] == "fisher":
     ctx.fisher_pairs_dev(d_counts, d_excl, d_src)
     ctx.sync()
     if os.environ.get("BH_STATS"):
-        h = d_src.download()
+        h = d_src.to_host()
         for c in (0, 7777, cols - 1):
             v, cnt = np.unique(h[:, c], return_counts=True)
             o = np.argsort(-cnt)[:8]
