@@ -63,7 +63,6 @@ struct BhsArgs {
     uint64_t* spill;        // [segs * m] scratch of the in-HBM bucket path (adversarial input only), bump-allocated
     unsigned long long* spill_n;
     int reg_cap;            // buckets beyond this many values take the in-HBM path (2048; lower in tests)
-    int ablate;             // timing experiments (param bh.ablate; results are wrong when set)
 };
 
 __device__ __forceinline__ uint64_t key_of(double v) {
@@ -1308,7 +1307,6 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm,
         if (B > MAX_B) B = MAX_B;
     }
     a.B = B;
-    a.ablate = (int)ctx->param("bh.ablate", 0);
     a.reg_cap = (int)std::min<int64_t>(2048, std::max<int64_t>(0, ctx->param("bh.reg_cap", 2048)));
     a.spb = (int)ctx->param("bh.spb", 8);
     if (a.spb < 1) a.spb = 1;
