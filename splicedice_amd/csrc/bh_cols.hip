@@ -451,8 +451,11 @@ __device__ __forceinline__ BucketRef bucket_ref(const BhsArgs& a, int64_t g) {
 // ranks a large bucket at K = 4 values per thread (48 VGPRs) where one wave per bucket would need 16 and more per lane.
 // Workgroup barriers between the phases; the resolving loop's trip count stays per WAVE (the largest mixed bin among ITS
 // values).  LDS: L[NS] (8 B) | CNT[2 NS + 4] (4 B) | wred[32] (8 B) | wtot[16] (4 B) | hv[4] (4 B) = 16 NS + 352 bytes.
-template <int T, int K>
-__device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef& r, uint64_t* smem) {
+// ZOOM: with the second-level pass for crowded bins (below).  Without it -- the main kernel, which keeps to 64 VGPRs and
+// eight waves per SIMD: with the pass inlined it needs 74, runs six, and takes 4.38 instead of 3.75 ms on a table that
+// never needs the pass -- a bucket that needs the pass is given back (false) and the caller lists it for the zoom kernel.
+template <int T, int K, bool ZOOM>
+__device__ __forceinline__ bool bucket_wg_rank(const BhsArgs& a, const BucketRef& r, uint64_t* smem) {
     constexpr int NS = T * K, BINS = 2 * NS, NW = T / 64;
     constexpr int LOGB = NS == 1024 ? 11 : NS == 2048 ? 12 : 13;
     static_assert(NS == 1024 || NS == 2048 || NS == 4096, "slots");
@@ -460,7 +463,7 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
     uint64_t* wred = L + NS;                                          // [2 NW]
     unsigned* CNT = reinterpret_cast<unsigned*>(wred + 32);          // [BINS + 4]
     unsigned* wtot = CNT + BINS + 4;                                  // [NW]
-    unsigned* hv = wtot + 16;                                         // [0] a bin beyond HEAVY exists, [1] work-list length
+    unsigned* hv = wtot + 16;                                         // [0] a bin beyond HEAVY exists, [1] mixed ones among them
     constexpr int HEAVY = 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_b = r.n_b;
@@ -499,7 +502,7 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
         for (int k = 0; k < K; ++k)
             if (ok[k]) r.ks[k * T + tid] = last;
         if (tid == 0) *r.bm = last;
-        return;
+        return true;
     }
     const int bits = 64 - __builtin_clzll(range);
     const int sh = __builtin_amdgcn_readfirstlane(bits > LOGB ? bits - LOGB : 0);
@@ -572,48 +575,134 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
         if (!mixed) cb[k] = 0;
     }
     // The resolving loop below runs, for a whole wave, once per member of the FULLEST mixed bin among the wave's values.
-    // Where the values crowd inside a bucket (Fisher's p-values just below 1; any spike narrower than a bin) one bin of a
-    // hundred members would hold all four waves for a hundred trips.  The members of mixed bins beyond HEAVY leave the
-    // loop: they go to a work list (over the bin counters, which are dead by now), and every listed value is counted by
-    // FOUR lanes that share its bin's members between them -- the work of a heavy bin is spread over the workgroup
-    // instead of being paid by every wave that holds one of its members.
-    int went[K];
+    // Where distinct values crowd inside a bucket far closer than a bin is wide (the bench's Fisher columns hold ~1 500
+    // sums within 10^-13 of 1, next to the exact ones) one bin of hundreds of members would hold all four waves for
+    // hundreds of trips.  The members of mixed bins beyond HEAVY entries leave the loop and are ranked by a SECOND counting
+    // sort inside their bin, with a window the bin's own members choose: centred on the bin's first member, as wide as 16 x
+    // the median distance of the next seven members from it (copies of it aside; a median: a stray ordinary value in the crowd's bin does not
+    // widen it), cut into SB sub-bins.  All heavy bins of the bucket share one array of NS sub-bin counters -- the bin
+    // counters are dead by now -- and one scan; the listed keys are rewritten into their bin's stretch of L in sub-bin
+    // order, a sub-bin of one repeated value is again ranked by position alone, and what is left (mixed sub-bins: a few
+    // members each) is counted by the owner.  (block-uniform decisions throughout; six more barriers, for ~2 % of the
+    // buckets of the bench's table)
+    if (heavy_path && !ZOOM) {
+        bool any = false;
 #pragma unroll
-    for (int k = 0; k < K; ++k) went[k] = -1;
-    if (heavy_path) {
-        uint64_t* WL = reinterpret_cast<uint64_t*>(CNT);          // [<= NS] start | count << 16 | slot << 32, then the result
-        __syncthreads();                                           // every read of the bin counters is done
+        for (int k = 0; k < K; ++k) any = any || cb[k] > HEAVY;
+        if (any) hv[1] = 1u;
+        __syncthreads();
+        if (hv[1] != 0u) return false;
+    }
+    if (heavy_path && ZOOM) {
+        unsigned* SC = CNT;                         // [NS + 1] sub-bin counters, then their exclusive scan (top bit: mixed)
+        unsigned* HT = CNT + NS + 1;                // [NS] by bin start: heavy-bin index | median distance exponent << 16
+        bool lst[K];
+        __syncthreads();                            // every read of the bin counters is done
+        for (int i = tid; i < NS + 1; i += T) SC[i] = 0u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (cb[k] > HEAVY) {
-                went[k] = (int)atomicAdd(&hv[1], 1u);
-                WL[went[k]] = (uint64_t)(unsigned)sb[k] | ((uint64_t)(unsigned)cb[k] << 16) | ((uint64_t)slot[k] << 32);
-                cb[k] = 0;
-            }
-        }
-        __syncthreads();
-        const int nwl = (int)hv[1];
-        const int q = lane & 3;
-        for (int e0 = wave * 16; e0 < nwl; e0 += NW * 16) {        // (wave-uniform) 16 listed values per wave and round
-            const int e = e0 + (lane >> 2);
-            const uint64_t w = e < nwl ? WL[e] : 0ull;
-            const int s0 = (int)(w & 0xffffu), c = (int)((w >> 16) & 0xffffu);
-            const unsigned sl = (unsigned)(w >> 32);
-            const uint64_t kk = L[s0 + (int)sl];
-            unsigned cnt = 0u;
-            for (int j = q; __ballot(j < c) != 0ull; j += 4) {
-                const bool in = j < c;
-                const uint64_t kj = L[s0 + (in ? j : 0)];
-                count_less96(cnt, in ? kj : ~0ull, in ? (unsigned)j : ~0u, kk, sl);
-            }
-            cnt += __shfl_xor(cnt, 1);
-            cnt += __shfl_xor(cnt, 2);
-            if (e < nwl && q == 0) WL[e] = (uint64_t)cnt;
-        }
-        __syncthreads();
+            lst[k] = cb[k] > HEAVY;
+            if (lst[k] && slot[k] == 0u) {          // the bin's first member (L[sb] is its own key) sizes the window
+                unsigned e[7], nz = 0u;                 // (copies of the first member itself say nothing about the spread)
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (went[k] >= 0) before[k] = (unsigned)WL[went[k]];
+                for (int j = 0; j < 7; ++j) {
+                    const uint64_t kj = L[sb[k] + 1 + j];
+                    const uint64_t d = kj > key[k] ? kj - key[k] : key[k] - kj;
+                    e[j] = d != 0ull ? 63u - (unsigned)__builtin_clzll(d) : 64u;
+                    nz += d != 0ull ? 1u : 0u;
+                }
+#define BH_CE(x, y) { const unsigned lo_ = e[x] < e[y] ? e[x] : e[y]; e[y] = e[x] < e[y] ? e[y] : e[x]; e[x] = lo_; }
+                BH_CE(0, 6) BH_CE(2, 3) BH_CE(4, 5) BH_CE(0, 2) BH_CE(1, 4) BH_CE(3, 6) BH_CE(0, 1) BH_CE(2, 5)
+                BH_CE(3, 4) BH_CE(1, 2) BH_CE(4, 6) BH_CE(2, 3) BH_CE(4, 5) BH_CE(1, 2) BH_CE(3, 4) BH_CE(5, 6)
+#undef BH_CE
+                const unsigned mi = nz >> 1;            // the median of the nz distances that are not zero (sorted first)
+                unsigned med = e[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) med = mi == (unsigned)j ? e[j] : med;
+                if (nz == 0u) med = 0u;
+                HT[sb[k]] = atomicAdd(&hv[1], 1u) | (med << 16);
+            }
+        }
+        __syncthreads();
+        const int n_heavy = (int)hv[1];
+        if (n_heavy > 0) {                          // (a heavy bin of ONE value is not mixed: nothing listed)
+            // every heavy bin holds more than HEAVY values: n_heavy <= NS / 9, SB >= 8, n_heavy x SB <= NS
+            const int sbl = 31 - __builtin_clz((unsigned)(NS / n_heavy));
+            const unsigned half = 1u << (sbl - 1);
+            unsigned sub[K], ss[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                sub[k] = 0u; ss[k] = 0u;
+                if (lst[k]) {
+                    const unsigned ht = HT[sb[k]];
+                    const uint64_t ref = L[sb[k]];
+                    const int s2 = (int)(ht >> 16) + 5 - sbl;          // window 2^(exponent + 5) wide, SB sub-bins
+                    const int sh2 = s2 > 0 ? s2 : 0;
+                    unsigned in_bin;                                    // monotone in the key, saturating at both ends
+                    if (key[k] >= ref) {
+                        const uint64_t d = (key[k] - ref) >> sh2;
+                        in_bin = half + (unsigned)(d < (uint64_t)(half - 1u) ? d : (uint64_t)(half - 1u));
+                    } else {
+                        const uint64_t d = (ref - key[k] - 1ull) >> sh2;
+                        in_bin = half - 1u - (unsigned)(d < (uint64_t)(half - 1u) ? d : (uint64_t)(half - 1u));
+                    }
+                    sub[k] = ((ht & 0xffffu) << sbl) + in_bin;
+                    ss[k] = atomicAdd(&SC[sub[k]], 1u);
+                }
+            }
+            __syncthreads();
+            {   // exclusive scan over the NS sub-bin counters: thread t owns [K t, K t + K)
+                unsigned c[K], tot = 0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) { c[j] = SC[tid * K + j]; tot += c[j]; }
+                unsigned x = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+                if (lane == 63) wtot[wave] = x;
+                __syncthreads();
+                unsigned pre = x - tot;
+                for (int w = 0; w < wave; ++w) pre += wtot[w];
+#pragma unroll
+                for (int j = 0; j < K; ++j) { SC[tid * K + j] = pre; pre += c[j]; }
+                if (tid == T - 1) SC[NS] = pre;
+            }
+            __syncthreads();
+            unsigned g0[K], cs[K], pos[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                g0[k] = 0u; cs[k] = 0u; pos[k] = 0u;
+                if (lst[k]) {
+                    const unsigned g = SC[sub[k]];
+                    cs[k] = SC[sub[k] + 1] - g;
+                    g0[k] = g - SC[(sub[k] >> sbl) << sbl];            // the sub-bin's start inside its bin
+                    pos[k] = g0[k] + ss[k];
+                    L[sb[k] + (int)pos[k]] = key[k];                    // (the stretch of a heavy bin is read by its members only,
+                }                                                       //  and their reads of it lie before the last barrier)
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (lst[k] && L[sb[k] + (int)g0[k]] != key[k]) atomicOr(&SC[sub[k]], 0x80000000u);
+            __syncthreads();
+            unsigned smax = 0u, cnt[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                cnt[k] = 0u;
+                if (!lst[k] || (SC[sub[k]] & 0x80000000u) == 0u) { cnt[k] = ss[k]; cs[k] = 0u; }
+                smax = cs[k] > smax ? cs[k] : smax;
+            }
+            for (unsigned i = 0; __ballot(i < smax) != 0ull; ++i) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool in = i < cs[k];
+                    const uint64_t kj = L[sb[k] + (int)g0[k] + (int)(in ? i : 0u)];
+                    count_less96(cnt[k], in ? kj : ~0ull, in ? g0[k] + i : ~0u, key[k], pos[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (lst[k]) { before[k] = g0[k] + cnt[k]; cb[k] = 0; }
+        }
     }
     int cmax = 0;
 #pragma unroll
@@ -675,10 +764,12 @@ __device__ __forceinline__ void bucket_wg_rank(const BhsArgs& a, const BucketRef
 #pragma unroll
     for (int k = 0; k < K; ++k)
         if (ok[k]) r.ks[k * T + tid] = L[rank[k]];        // in place: the slot the key came from
+    return true;
 }
 template <int T, int K> constexpr size_t bucket_wg_lds() { return (size_t)T * K * 16 + 16 + 32 * 8 + 16 * 4 + 16; }
 
-// one workgroup of T threads per bucket of up to 4 T values; larger ones go to the work list of the second kernel.
+// one workgroup of T threads per bucket of up to 4 T values; larger ones, and the few with a crowded bin (see ZOOM), go to
+// the work list of the second kernel.
 // Workgroups are dealt round-robin over the 8 XCDs: all buckets of one column go to workgroups of ONE XCD (column mod
 // 8), next to the tiles that filled them.
 template <int T>
@@ -688,12 +779,12 @@ __global__ void __launch_bounds__(T) bhs_bucket_kernel(BhsArgs a) {
     const int64_t seg_x = (k / a.B) * 8 + (blockIdx.x & 7);
     if (seg_x >= a.segs) return;
     const BucketRef r = bucket_ref(a, seg_x * a.B + k % a.B);
-    if (r.n_b <= 4 * T && r.n_b <= a.reg_cap) bucket_wg_rank<T, 4>(a, r, smem_bk);
-    else if (threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1u)] = seg_x * a.B + k % a.B;
+    const bool done = r.n_b <= 4 * T && r.n_b <= a.reg_cap && bucket_wg_rank<T, 4, false>(a, r, smem_bk);      // (block-uniform)
+    if (!done && threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1u)] = seg_x * a.B + k % a.B;
 }
 
-// the listed buckets in turn: up to 2048 values by the workgroup (8 per thread), beyond that (or beyond bh.reg_cap) by
-// its first wave in HBM.  (Workgroups of 512 / 1024 threads for the large buckets were measured: the barriers between
+// the listed buckets in turn: up to 2048 values by the workgroup (8 per thread, with the second-level pass for crowded
+// bins), beyond that (or beyond bh.reg_cap) by its first wave in HBM.  (Workgroups of 512 / 1024 threads for the large buckets were measured: the barriers between
 // the phases cost more than the larger bucket saves -- DESIGN.md appendix A.4.)
 __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
     extern __shared__ uint64_t smem_bk[];
@@ -701,11 +792,25 @@ __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
 #pragma nounroll
     for (unsigned w = blockIdx.x; w < n_big; w += gridDim.x) {
         const BucketRef r = bucket_ref(a, a.big_list[w]);
+        if (r.n_b <= 1024 && r.n_b <= a.reg_cap) continue;            // (block-uniform) bhs_bucket_zoom_kernel's
         if ((r.n_b > a.reg_cap && !r.pd) || r.n_b > 2048) {
             if (threadIdx.x < 64) bucket_in_hbm(a, r.ks, r.n_b, r.start, (int)threadIdx.x, r.bm);
         } else {
-            bucket_wg_rank<256, 8>(a, r, smem_bk);
+            bucket_wg_rank<256, 8, true>(a, r, smem_bk);
         }
+        __syncthreads();
+    }
+}
+
+// the listed buckets of up to 1024 values -- the main kernel gave them back for their crowded bins -- at 4 values per thread
+// with the second-level pass: 74 VGPRs, six waves per SIMD, where the 8-per-thread kernel above runs two
+__global__ void __launch_bounds__(256) bhs_bucket_zoom_kernel(BhsArgs a) {
+    extern __shared__ uint64_t smem_bk[];
+    const unsigned n_big = *a.big_count;
+#pragma nounroll
+    for (unsigned w = blockIdx.x; w < n_big; w += gridDim.x) {
+        const BucketRef r = bucket_ref(a, a.big_list[w]);
+        if (r.n_b <= 1024 && r.n_b <= a.reg_cap) bucket_wg_rank<256, 4, true>(a, r, smem_bk);
         __syncthreads();
     }
 }
@@ -1383,6 +1488,7 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm,
     }
     const int64_t big_blocks = std::max<int64_t>(1, std::min<int64_t>(n_buckets, (int64_t)ctx->n_cu * 4));
     SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel, dim3((unsigned)big_blocks), dim3(256), (bucket_wg_lds<256, 8>()), a);
+    SD_LAUNCH(ctx, "bhs_bucket_zoom_kernel", bhs_bucket_zoom_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_buckets, (int64_t)ctx->n_cu * 6))), dim3(256), (bucket_wg_lds<256, 4>()), a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);
     // bh.finish_cols: columns per workgroup of the last kernel (16: full 128-byte lines out, 3.2 MB of results per strip
     // at 25 000 rows; 8: half lines, half the L2 footprint of the gather); bh.finish_nt: non-temporal gather loads
