@@ -273,6 +273,27 @@ int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const int32_t* r
                       const int32_t* row_right, const int8_t* row_strand, int64_t n_q,
                       const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
                       const int8_t* q_strand, int32_t* row_out, int threads);
+/* One sample's column of the count table (SPLICEDICE.getJunctionCounts, SPLICEDICE.py:257-295: later lines of a file
+ * overwrite earlier ones, no score filter): col[row] = score for every line whose junction is among the rows, in line
+ * order.  col: the sample's int32 [n_rows] stretch of the TRANSPOSED table [sample][row], zeroed by the caller;
+ * low (or NULL): set to 1 where a line with score < min_unique hits the row.  A final value outside [0, 2^31) is
+ * SDICE_ERR_ARG ("junction counts must be non-negative and below 2**31", the reference's int conversion limit here).
+ * Single-threaded: one call per sample, side by side.  sdice_transpose_i32: dst[c][r] = src[r][c] (threads).
+ * sdice_host_threads: the default worker count of the host-side calls (hardware threads capped by the cgroup quota). */
+int sdice_junc_count_column(int64_t n_rows, const int32_t* row_chrom, const int32_t* row_left,
+                            const int32_t* row_right, const int8_t* row_strand, int64_t n_q,
+                            const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
+                            const int8_t* q_strand, const int64_t* score, int32_t min_unique, int32_t* col,
+                            uint8_t* low);
+/* Second step of the ingest, per file (the junction set of SPLICEDICE.getAllJunctions, SPLICEDICE.py:147-228):
+ * chrom_rank[i] = rank_of_chrom[chrom_id[i]], and the admitted lines' keys, packed order-preservingly as
+ * chrom 12 | left 31 | right - left 20 | strand 1 bits, compacted into keys_out (room for n; input of
+ * sdice_sort_unique_u64).  *packable = 0 when an admitted junction does not fit the packing. */
+int sdice_junc_pack_keys(int64_t n, const int32_t* chrom_id, const int32_t* rank_of_chrom, int32_t n_chroms,
+                         const int32_t* left, const int32_t* right, const int8_t* strand, const uint8_t* admit,
+                         int32_t* chrom_rank, uint64_t* keys_out, int64_t* n_keys, int32_t* packable);
+int sdice_transpose_i32(int64_t rows, int64_t cols, const int32_t* src, int32_t* dst, int threads);
+int sdice_host_threads(void);
 
 /* ---- K0: sorted set of 64-bit keys, in place: the junction union of `quant`
  * (`self.junctions.add(...)` over every sample file + `sorted(self.junctions)`, SPLICEDICE.py:147-228,

@@ -77,6 +77,10 @@ SIGNATURES = {
                         C.c_int],
     "sdice_junc_close": [vp],
     "sdice_junc_lookup": [C.c_int64, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int],
+    "sdice_junc_count_column": [C.c_int64, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, vp, vp],
+    "sdice_junc_pack_keys": [C.c_int64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, c_i64p, C.POINTER(C.c_int32)],
+    "sdice_transpose_i32": [C.c_int64, C.c_int64, vp, vp, C.c_int],
+    "sdice_host_threads": [],
     "sdice_sort_unique_u64": [ctxp, C.c_int64, vp, c_i64p],
     "sdice_similarity": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],
     "sdice_similarity_dev": [ctxp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp],

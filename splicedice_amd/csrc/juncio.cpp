@@ -76,8 +76,32 @@ inline bool to_i64(Field f, int64_t& v) {
     return r.ec == std::errc() && r.ptr == f.b;
 }
 
+// float(text) for the entropy fields.  Plain decimals of up to 15 significant digits -- "1.50", what bam_to_junc_bed
+// writes -- take the exact route: the digits as an integer below 2^53 divided by a power of ten up to 10^22, both exact
+// doubles, so the one IEEE division is the correctly rounded value, the same double that from_chars (and Python's float())
+// returns.  Everything else (exponents, long digit strings, inf / nan, a bare '.') goes to from_chars.
 inline bool to_f64(const char* a, const char* b, double& v) {
     if (a < b && *a == '+') ++a;
+    static const double P10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    {
+        const char* p = a;
+        const bool neg = p < b && *p == '-';
+        if (neg) ++p;
+        uint64_t m = 0;
+        int nd = 0, frac = 0;
+        bool dot = false, plain = p < b;
+        for (; p < b; ++p) {
+            const unsigned d = (unsigned)(*p - '0');
+            if (d <= 9u) { m = m * 10u + d; ++nd; frac += dot ? 1 : 0; }
+            else if (*p == '.' && !dot) dot = true;
+            else { plain = false; break; }
+        }
+        if (plain && nd >= 1 && nd <= 15) {
+            const double x = (double)m / P10[frac];
+            v = neg ? -x : x;
+            return true;
+        }
+    }
     auto r = std::from_chars(a, b, v);
     return r.ec == std::errc() && r.ptr == b;
 }
@@ -123,6 +147,7 @@ extern "C" int sdice_junc_open(const char* path, int type, sdice_juncfile** out,
         t->base = (const char*)m;
     }
     size_t pos = 0;
+    t->line_start.reserve(t->size / 32 + 2);
     while (pos < t->size) {
         t->line_start.push_back(pos);
         const char* e = (const char*)memchr(t->base + pos, '\n', t->size - pos);
@@ -346,5 +371,147 @@ extern "C" int sdice_junc_lookup(int64_t n_rows, const int32_t* row_chrom, const
     return SDICE_ERR_NOMEM;
 } catch (...) {
     sdice_set_error("sdice_junc_lookup: unknown exception");
+    return SDICE_ERR_STATE;
+}
+
+// One sample's column of the count table (SPLICEDICE.getJunctionCounts, SPLICEDICE.py:257-295: counts[junction][sample] =
+// score; a later line of the file overwrites an earlier one, and no score filter applies): col[row] = score for every
+// line whose junction is among the rows, in line order.  `col` is the sample's int32 [n_rows] stretch of the TRANSPOSED
+// table, zeroed by the caller -- a sample writes 4 n_rows contiguous bytes instead of one word in each of n_rows lines of
+// the [row][sample] table -- and sdice_transpose_i32 turns the finished table.  low (or NULL): set to 1 where a line with
+// score < min_unique hits the row (it stays set when a later line raises the count).  A FINAL value outside [0, 2^31) is
+// an error.  Single-threaded: the caller runs one call per sample side by side.
+extern "C" int sdice_junc_count_column(int64_t n_rows, const int32_t* row_chrom, const int32_t* row_left,
+                                       const int32_t* row_right, const int8_t* row_strand, int64_t n_q,
+                                       const int32_t* q_chrom, const int32_t* q_left, const int32_t* q_right,
+                                       const int8_t* q_strand, const int64_t* score, int32_t min_unique, int32_t* col,
+                                       uint8_t* low) try {
+    if (n_rows < 0 || n_q < 0 || (n_q > 0 && (!q_chrom || !q_left || !q_right || !q_strand || !score)) || (n_rows > 0 && !col)) {
+        sdice_set_error("sdice_junc_count_column: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    constexpr int32_t BAD = INT32_MIN;          // (a value that no admissible count takes) marks a row whose last value is out of range
+    int64_t n_bad = 0;
+    int64_t hint = 0;                           // files are sorted by coordinate as a rule: the next junction is the next row or near it
+    for (int64_t i = 0; i < n_q; ++i) {
+        const int32_t c = q_chrom[i], l = q_left[i], rr = q_right[i];
+        const int8_t st = q_strand[i];
+        auto cmp = [&](int64_t r) {             // rows[r] <=> query: -1, 0, 1
+            if (row_chrom[r] != c) return row_chrom[r] < c ? -1 : 1;
+            if (row_left[r] != l) return row_left[r] < l ? -1 : 1;
+            if (row_right[r] != rr) return row_right[r] < rr ? -1 : 1;
+            if (row_strand[r] != st) return row_strand[r] < st ? -1 : 1;
+            return 0;
+        };
+        int64_t lo = 0, hi = n_rows;
+        if (hint < n_rows) {                    // gallop from the previous hit
+            const int h = cmp(hint);
+            if (h == 0) { lo = hint; hi = hint; }
+            else if (h < 0) {
+                int64_t step = 1, a = hint + 1;
+                while (a < n_rows && cmp(a) < 0) { lo = a + 1; a += step; step <<= 1; }
+                if (lo < hint + 1) lo = hint + 1;
+                hi = a < n_rows ? a : n_rows;
+            } else {
+                hi = hint;
+            }
+        }
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (cmp(mid) < 0) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= n_rows || c < 0 || cmp(lo) != 0) continue;
+        hint = lo + 1;
+        const int64_t v = score[i];
+        if (col[lo] == BAD) --n_bad;
+        if (v < 0 || v > (int64_t)INT32_MAX) { col[lo] = BAD; ++n_bad; }
+        else col[lo] = (int32_t)v;
+        if (low && v < (int64_t)min_unique) low[lo] = 1;
+    }
+    if (n_bad > 0) {
+        sdice_set_error("junction counts must be non-negative and below 2**31");
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junc_count_column: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junc_count_column: unknown exception");
+    return SDICE_ERR_STATE;
+}
+
+// dst[c][r] = src[r][c] for an int32 table of `rows` x `cols` (blocks of 64 x 64 words, threads over the blocks of rows)
+extern "C" int sdice_transpose_i32(int64_t rows, int64_t cols, const int32_t* src, int32_t* dst, int threads) try {
+    if (rows < 0 || cols < 0 || (rows > 0 && cols > 0 && (!src || !dst))) { sdice_set_error("sdice_transpose_i32: bad arguments"); return SDICE_ERR_ARG; }
+    int nthreads = threads > 0 ? threads : sd_default_threads();
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    constexpr int64_t BL = 64;
+    const int64_t cblocks = (cols + BL - 1) / BL;
+    if (rows * cols < (int64_t)1 << 20 || cblocks < nthreads) nthreads = 1;
+    auto work = [&](int64_t cb0, int64_t cb1) {          // a thread owns whole stretches of dst rows
+        for (int64_t cb = cb0; cb < cb1; ++cb) {
+            const int64_t c0 = cb * BL, c1 = std::min(cols, c0 + BL);
+            for (int64_t r0 = 0; r0 < rows; r0 += BL) {
+                const int64_t r1 = std::min(rows, r0 + BL);
+                for (int64_t c = c0; c < c1; ++c) {
+                    int32_t* d = dst + c * rows;
+                    for (int64_t r = r0; r < r1; ++r) d[r] = src[r * cols + c];
+                }
+            }
+        }
+    };
+    if (nthreads == 1) {
+        work(0, cblocks);
+    } else {
+        std::vector<std::thread> pool;
+        JoinAll joiner{pool};
+        for (int k = 0; k < nthreads; ++k) pool.emplace_back(work, cblocks * k / nthreads, cblocks * (k + 1) / nthreads);
+    }
+    return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_transpose_i32: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_transpose_i32: unknown exception");
+    return SDICE_ERR_STATE;
+}
+
+// worker threads the host-side calls use by default: hardware threads capped by the cgroup's CPU quota
+extern "C" int sdice_host_threads(void) { return sd_default_threads(); }
+
+// Second step of the ingest, per file (SPLICEDICE.getAllJunctions adds (chrom, left, right, strand) to one set and sorts
+// it, SPLICEDICE.py:147-228): chrom_rank[i] = rank_of_chrom[chrom_id[i]] (the file's chromosome table mapped to the ranks of
+// the names in the sorted union of all files' tables), and the admitted lines' keys in the order-preserving packing
+// chrom 12 | left 31 | right - left 20 | strand 1 bits, compacted into keys_out (room for n).  *packable = 0 when an
+// admitted junction does not fit the packing (the caller then sorts tuples on the host); *n_keys = keys written.
+extern "C" int sdice_junc_pack_keys(int64_t n, const int32_t* chrom_id, const int32_t* rank_of_chrom, int32_t n_chroms,
+                                    const int32_t* left, const int32_t* right, const int8_t* strand, const uint8_t* admit,
+                                    int32_t* chrom_rank, uint64_t* keys_out, int64_t* n_keys, int32_t* packable) try {
+    if (n < 0 || !n_keys || !packable || (n > 0 && (!chrom_id || !rank_of_chrom || !left || !right || !strand || !admit || !chrom_rank || !keys_out))) {
+        sdice_set_error("sdice_junc_pack_keys: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    int64_t k = 0;
+    bool fits = true;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = chrom_id[i];
+        if (ci < 0 || ci >= n_chroms) { sdice_set_error("sdice_junc_pack_keys: chromosome index out of range"); return SDICE_ERR_ARG; }
+        const int32_t c = rank_of_chrom[ci];
+        chrom_rank[i] = c;
+        if (!admit[i]) continue;
+        const int64_t l = left[i], span = (int64_t)right[i] - l;
+        if (c < 0 || c >= (1 << 12) || l < 0 || span < 0 || span >= ((int64_t)1 << 20)) { fits = false; continue; }
+        keys_out[k++] = ((uint64_t)c << 52) | ((uint64_t)l << 21) | ((uint64_t)span << 1) | (uint64_t)(strand[i] & 1);
+    }
+    *n_keys = k;
+    *packable = fits ? 1 : 0;
+    return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junc_pack_keys: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junc_pack_keys: unknown exception");
     return SDICE_ERR_STATE;
 }

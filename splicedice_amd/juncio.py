@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _ffi
+from . import _ffi, _stages
 
 TYPE_CODE = {"bed": 0, "leafcutter": 0, "splicedicebed": 1, "SJ": 2}   # other types contribute nothing (:23-36)
 
@@ -63,21 +63,29 @@ _SPAN_BITS, _LEFT_BITS, _CHROM_BITS = 20, 31, 12
 
 def _union_packed(ctx, recs):
     """Sorted junction union through sdice_sort_unique_u64, or None when a junction does not fit the
-    packing (more than 4096 chromosomes, span >= 2^20, negative coordinates)."""
-    parts = []
-    for rec in recs:
-        a = rec["admit"].astype(bool)
-        if not a.any():
-            continue
-        c, l, r = rec["chrom_rank"][a].astype(np.int64), rec["left"][a].astype(np.int64), rec["right"][a].astype(np.int64)
-        span = r - l
-        if c.max() >= 1 << _CHROM_BITS or l.min() < 0 or span.min() < 0 or span.max() >= 1 << _SPAN_BITS:
-            return None
-        parts.append(((c << (_LEFT_BITS + _SPAN_BITS + 1)) | (l << (_SPAN_BITS + 1)) | (span << 1)
-                      | rec["strand"][a].astype(np.int64)).astype(np.uint64))
+    packing (more than 4096 chromosomes, span >= 2^20, negative coordinates).  recs carry "keys" / "packable" from
+    _rank_and_pack."""
+    if not all(rec["packable"] for rec in recs):
+        return None
+    parts = [rec["keys"] for rec in recs if rec["keys"].size]
     if not parts:
         return tuple(np.zeros(0, d) for d in (np.int32, np.int32, np.int32, np.int8))
     return _unpack_keys(ctx.sort_unique_u64(np.concatenate(parts)))
+
+
+def _rank_and_pack(rec, rank):
+    """rec["chrom_rank"] (the file's chromosome table mapped to the ranks of the sorted union of names) and the admitted
+    lines' packed keys: one library call per file, the calls side by side (sdice_junc_pack_keys)."""
+    lib = _ffi.load()
+    local = np.fromiter((rank[c] for c in rec["chroms"]), dtype=np.int32, count=len(rec["chroms"]))
+    n = rec["chrom_id"].size
+    rec["chrom_rank"] = np.empty(n, np.int32)
+    keys = np.empty(n, np.uint64)
+    nk, ok = C.c_int64(), C.c_int32()
+    _ffi.check(lib.sdice_junc_pack_keys(n, _vp(rec["chrom_id"]), _vp(local), local.size, _vp(rec["left"]), _vp(rec["right"]),
+                                        _vp(rec["strand"]), _vp(rec["admit"]), _vp(rec["chrom_rank"]), _vp(keys), C.byref(nk),
+                                        C.byref(ok)), "sdice_junc_pack_keys")
+    rec["keys"], rec["packable"] = keys[:nk.value], bool(ok.value)
 
 
 def _unpack_keys(keys):
@@ -96,21 +104,21 @@ def ingest(manifest, args, ctx=None):
     (chrom_rank, left, right, strand), parsed per-sample records with global chromosome ranks).
     With an engine context the union / sort of the junction set runs on the GPU."""
     # the files are parsed concurrently (the library call releases the GIL); results keep manifest order
-    import os
     from concurrent.futures import ThreadPoolExecutor
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(len(manifest), cores, 16))
+    cores = host_threads()
+    workers = max(1, min(len(manifest), cores))
     per_file = max(1, cores // workers)
 
     def _one(sample):
         code = TYPE_CODE.get(sample.type)
         return parse_sample(sample.filename, code, args, per_file) if code is not None else None
 
-    if workers > 1:
-        with ThreadPoolExecutor(workers) as pool:
-            parsed = list(pool.map(_one, manifest))
-    else:
-        parsed = [_one(sample) for sample in manifest]
+    with _stages.stage("parse:files"):
+        if workers > 1:
+            with ThreadPoolExecutor(workers) as pool:
+                parsed = list(pool.map(_one, manifest))
+        else:
+            parsed = [_one(sample) for sample in manifest]
     all_names = set()
     for rec in parsed:
         if rec is not None:
@@ -118,14 +126,20 @@ def ingest(manifest, args, ctx=None):
     names = sorted(all_names)                     # Python string order, as the reference's tuple sorts
     rank = {c: i for i, c in enumerate(names)}
     keys = []
-    for rec in parsed:
-        if rec is None:
-            continue
-        local = np.fromiter((rank[c] for c in rec["chroms"]), dtype=np.int32, count=len(rec["chroms"]))
-        rec["chrom_rank"] = local[rec["chrom_id"]] if rec["chrom_id"].size else np.zeros(0, np.int32)
+    present = [rec for rec in parsed if rec is not None]
+    with _stages.stage("parse:keys"):
+        if workers > 1:
+            with ThreadPoolExecutor(workers) as pool:
+                list(pool.map(lambda rec: _rank_and_pack(rec, rank), present))
+        else:
+            for rec in present:
+                _rank_and_pack(rec, rank)
     if ctx is not None:
-        junc = _union_packed(ctx, [rec for rec in parsed if rec is not None])
+        with _stages.stage("parse:union"):
+            junc = _union_packed(ctx, present)
         if junc is not None:
+            for rec in present:
+                del rec["keys"]
             return names, junc, parsed
     for rec in parsed:
         if rec is None:
@@ -154,23 +168,47 @@ def ingest(manifest, args, ctx=None):
     return names, junc, parsed
 
 
+def host_threads():
+    """worker threads for host-side work: hardware threads capped by the cgroup's CPU quota (the library's own default)"""
+    return max(1, int(_ffi.load().sdice_host_threads()))
+
+
 def gather_counts(manifest, parsed, rows, args):
     """counts int32 [N, S] + flat `low` indices; later lines overwrite earlier ones, no score filter
-    (SPLICEDICE.py:257-295)."""
+    (SPLICEDICE.py:257-295).  Every sample fills its own contiguous stretch of the TRANSPOSED table (one library call per
+    sample, the calls side by side: look-up and store in one pass, sdice_junc_count_column); one threaded transpose
+    gives the [junction][sample] table."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _ffi.load()
     n, s = rows[0].size, len(manifest)
-    counts = np.zeros((n, s), dtype=np.int64)
-    low = []
-    for si, (sample, rec) in enumerate(zip(manifest, parsed)):
+    rc_, rl, rr, rs = (np.ascontiguousarray(a, dtype=d) for a, d in zip(rows, (np.int32, np.int32, np.int32, np.int8)))
+    counts_t = np.zeros((s, n), dtype=np.int32)
+    want_low = [bool(args.lowCoverageNan and sample.type != "SJ") for sample in manifest]
+    low_t = {si: np.zeros(n, dtype=np.uint8) for si in range(s) if want_low[si]}
+
+    def _one(si):
+        rec = parsed[si]
         if rec is None or rec["left"].size == 0:
-            continue
-        idx = lookup_rows(rows, rec["chrom_rank"], rec["left"], rec["right"], rec["strand"])
-        ok = idx >= 0
-        counts[idx[ok], si] = rec["score"][ok]          # repeated rows: the last line wins
-        if args.lowCoverageNan and sample.type != "SJ":
-            lo = ok & (rec["score"] < args.minUnique)
-            if lo.any():
-                # a row marked low by an earlier line stays marked even if a later line raises the count
-                low.append(np.unique(idx[lo]).astype(np.int64) * s + si)
-    if counts.size and (counts.min() < 0 or counts.max() >= 2 ** 31):
-        raise ValueError("junction counts must be non-negative and below 2**31")
-    return counts.astype(np.int32), (np.concatenate(low) if low else np.zeros(0, np.int64))
+            return
+        qc, ql, qr = (np.ascontiguousarray(rec[k], dtype=np.int32) for k in ("chrom_rank", "left", "right"))
+        qs = np.ascontiguousarray(rec["strand"], dtype=np.int8)
+        sc = np.ascontiguousarray(rec["score"], dtype=np.int64)
+        low = low_t.get(si)
+        rc = lib.sdice_junc_count_column(n, _vp(rc_), _vp(rl), _vp(rr), _vp(rs), qc.size, _vp(qc), _vp(ql), _vp(qr), _vp(qs),
+                                         _vp(sc), int(args.minUnique), _vp(counts_t[si]), _vp(low) if low is not None else None)
+        if rc != 0:
+            raise ValueError(lib.sdice_last_error().decode())
+
+    with _stages.stage("parse:gather"):
+        workers = max(1, min(s, host_threads()))
+        if workers > 1:
+            with ThreadPoolExecutor(workers) as pool:
+                list(pool.map(_one, range(s)))
+        else:
+            for si in range(s):
+                _one(si)
+        counts = np.empty((n, s), dtype=np.int32)
+        _ffi.check(lib.sdice_transpose_i32(s, n, _vp(counts_t), _vp(counts), 0), "sdice_transpose_i32")
+    low = [np.flatnonzero(low_t[si]).astype(np.int64) * s + si for si in sorted(low_t)]
+    low = [x for x in low if x.size]
+    return counts, (np.concatenate(low) if low else np.zeros(0, np.int64))

@@ -209,3 +209,52 @@ def test_write_clusters(tmp_path):
     assert open(path).read() == want
     textio.write_clusters(path, [], np.zeros(1, np.int64), np.zeros(0, np.int32))
     assert open(path).read() == ""
+
+
+def test_count_column_and_transpose_against_numpy():
+    """sdice_junc_count_column (look-up + store of one sample's column, gallop from the previous hit) against the plain
+    numpy statement of SPLICEDICE.py:257-295 on unsorted lines with repeated and absent junctions; the out-of-range rule
+    looks at the FINAL value of a row, as the reference's check of the finished table does."""
+    import ctypes as C
+    from splicedice_amd import juncio, _ffi
+    lib = _ffi.load()
+    vp = juncio._vp
+    rng = np.random.default_rng(12)
+    n = 5000
+    keys = np.unique(rng.integers(0, 1 << 20, size=n))
+    rows = ((keys >> 16).astype(np.int32), ((keys >> 6) & 1023).astype(np.int32), ((keys >> 1) & 31).astype(np.int32) + 2000,
+            (keys & 1).astype(np.int8))
+    n = keys.size
+    for order in ("sorted", "shuffled"):
+        q = rng.integers(0, n, size=3 * n)
+        if order == "sorted":
+            q = np.sort(q)
+        qc, ql, qr, qs = (np.ascontiguousarray(a[q]) for a in rows)
+        absent = rng.random(q.size) < 0.1
+        qr = np.where(absent, qr + 100, qr).astype(np.int32)            # not among the rows
+        score = rng.integers(0, 50, size=q.size).astype(np.int64)
+        want = np.zeros(n, np.int64)
+        want_low = np.zeros(n, np.uint8)
+        for i in np.flatnonzero(~absent):
+            want[q[i]] = score[i]
+            if score[i] < 5:
+                want_low[q[i]] = 1
+        col, low = np.zeros(n, np.int32), np.zeros(n, np.uint8)
+        rc = lib.sdice_junc_count_column(n, vp(rows[0]), vp(rows[1]), vp(rows[2]), vp(rows[3]), q.size, vp(qc), vp(ql), vp(qr), vp(qs),
+                                         vp(score), 5, vp(col), vp(low))
+        assert rc == 0 and np.array_equal(col, want) and np.array_equal(low, want_low)
+    # a value beyond int32 that a later line replaces is fine; one that stays is the reference's error
+    qc, ql, qr, qs = (np.ascontiguousarray(a[[3, 3, 7]]) for a in rows)
+    col = np.zeros(n, np.int32)
+    sc = np.int64([1 << 40, 6, 9])
+    assert lib.sdice_junc_count_column(n, vp(rows[0]), vp(rows[1]), vp(rows[2]), vp(rows[3]), 3, vp(qc), vp(ql), vp(qr), vp(qs), vp(sc), 0, vp(col), None) == 0
+    assert col[3] == 6 and col[7] == 9
+    sc = np.int64([6, -1, 9])
+    assert lib.sdice_junc_count_column(n, vp(rows[0]), vp(rows[1]), vp(rows[2]), vp(rows[3]), 3, vp(qc), vp(ql), vp(qr), vp(qs), vp(sc), 0, vp(col), None) != 0
+    assert b"below 2**31" in lib.sdice_last_error()
+    for shape in ((3, 5), (100, 70_000), (257, 4099)):
+        src = rng.integers(-5, 1 << 30, size=shape).astype(np.int32)
+        dst = np.empty(shape[::-1], np.int32)
+        assert lib.sdice_transpose_i32(shape[0], shape[1], vp(src), vp(dst), 0) == 0
+        assert np.array_equal(dst, src.T)
+    assert lib.sdice_host_threads() >= 1

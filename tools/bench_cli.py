@@ -52,11 +52,17 @@ try:
     rng = np.random.default_rng(9)
     chrom_col = np.array(names)[cr]
     strand_col = np.array(["+", "-"])[strand]
+    # the lines of a file in the order bam_to_junc_bed writes them (`for junction in sorted(counts)`, bam_to_junc_bed.py:162:
+    # chromosome as a string, left, right, strand)
+    by_key = np.lexsort((strand_col, right, left, chrom_col))
+    rank_of = np.empty(nj, np.int64)
+    rank_of[by_key] = np.arange(nj)
     in_bytes = 0
     with open(os.path.join(d, "manifest.tsv"), "w") as mf:
         for s in range(ns):
             cnt = synth.make_counts(nj, 1, 900 + s, zero_frac=0.15)[:, 0]
             keep = np.flatnonzero(rng.random(nj) > 0.1)
+            keep = keep[np.argsort(rank_of[keep], kind="stable")]
             path = os.path.join(d, f"s{s}.junc.bed")
             # (vectorised text assembly: generation is not what is measured)
             cols = [chrom_col[keep], left[keep].astype(str), right[keep].astype(str),
