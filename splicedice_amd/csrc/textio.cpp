@@ -553,6 +553,55 @@ extern "C" int sdice_write_junction_bed(const char* path, int64_t n, const char*
     return SDICE_ERR_STATE;
 }
 
+// Row names 'chrom:left-right:strand' (SPLICEDICE.py:312-314) of n junction rows as one byte string + offsets, for the
+// table writers above (which take names in exactly this form): out (room for out_cap bytes) and off[n + 1].
+// strand: the symbol per row.  *need = bytes the names take (also when out_cap is too small: SDICE_ERR_ARG then).
+extern "C" int sdice_junction_names(int64_t n, const char* chrom_names, const int64_t* chrom_off, int32_t n_chrom,
+                                    const int32_t* chrom, const int32_t* left, const int32_t* right, const char* strand,
+                                    char* out, int64_t out_cap, int64_t* off, int64_t* need) try {
+    if (n < 0 || n_chrom < 0 || !off || (n > 0 && (!chrom_names || !chrom_off || !chrom || !left || !right || !strand))) {
+        sdice_set_error("sdice_junction_names: bad arguments");
+        return SDICE_ERR_ARG;
+    }
+    int64_t pos = 0;
+    bool fits = out != nullptr;
+    char num[16];
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t c = chrom[r];
+        if (c < 0 || c >= n_chrom) { sdice_set_error("sdice_junction_names: chromosome index out of range"); return SDICE_ERR_ARG; }
+        const int64_t cl = chrom_off[c + 1] - chrom_off[c];
+        off[r] = pos;
+        const auto l_end = std::to_chars(num, num + sizeof num, left[r]).ptr;
+        const int64_t ll = l_end - num;
+        char num2[16];
+        const int64_t rl = std::to_chars(num2, num2 + sizeof num2, right[r]).ptr - num2;
+        const int64_t len = cl + 1 + ll + 1 + rl + 2;
+        if (fits && pos + len <= out_cap) {
+            char* o = out + pos;
+            memcpy(o, chrom_names + chrom_off[c], (size_t)cl); o += cl;
+            *o++ = ':'; memcpy(o, num, (size_t)ll); o += ll;
+            *o++ = '-'; memcpy(o, num2, (size_t)rl); o += rl;
+            *o++ = ':'; *o++ = strand[r];
+        } else {
+            fits = false;
+        }
+        pos += len;
+    }
+    off[n] = pos;
+    if (need) *need = pos;
+    if (!fits && n > 0) {
+        sdice_set_error("sdice_junction_names: the names take %lld bytes, room for %lld", (long long)pos, (long long)out_cap);
+        return SDICE_ERR_ARG;
+    }
+    return SDICE_OK;
+} catch (const std::exception& e) {
+    sdice_set_error("sdice_junction_names: %s", e.what());
+    return SDICE_ERR_NOMEM;
+} catch (...) {
+    sdice_set_error("sdice_junction_names: unknown exception");
+    return SDICE_ERR_STATE;
+}
+
 // ------------------------------------------------------------------------------------------ reader
 struct sdice_table {
     int fd = -1;

@@ -113,9 +113,8 @@ class Quant:
             dst[row_of] = src                                  # row order (SPLICEDICE.py:96)
         self.rows = tuple(rows)
         self.chrom_names = chrom_names
-        self.junctions = [(chrom_names[c], int(l), int(r), textio.STRAND_SYM[s])
-                          for c, l, r, s in zip(*(a.tolist() for a in self.rows))]
-        self.names = [textio.junction_name(j) for j in self.junctions]
+        # 'chrom:left-right:strand' per row (SPLICEDICE.py:312-314), kept as one byte string + offsets for the writers
+        self.names = textio.junction_names(chrom_names, *self.rows)
         print("\tDone", timer.check())
 
         # Several ranks (python -m torch.distributed.run ... -m splicedice_amd quant): parsing and clustering

@@ -58,6 +58,85 @@ _DTYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int
 _MODE_CODE = {".3f": 0, ".0f": 1, "repr": 2}
 
 
+class NameTable:
+    """Row names as ONE byte string + offsets -- the form the library's writers take them in -- behaving as a read-only
+    sequence of str (names are decoded on demand).  A million names as a Python list cost ~1 s to build and ~0.3 s to
+    re-encode per written table."""
+
+    def __init__(self, blob, off):
+        self.blob = bytes(blob)
+        self.off = np.ascontiguousarray(off, dtype=np.int64)
+        assert self.off.ndim == 1 and self.off.size >= 1 and int(self.off[-1]) - int(self.off[0]) == len(self.blob)
+
+    def __len__(self):
+        return self.off.size - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            lo, hi, step = i.indices(len(self))
+            if step != 1:
+                return [self[k] for k in range(lo, hi, step)]
+            hi = max(hi, lo)
+            base = int(self.off[0])
+            return NameTable(self.blob[int(self.off[lo]) - base:int(self.off[hi]) - base], self.off[lo:hi + 1])
+        n = len(self)
+        i = int(i)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        base = int(self.off[0])
+        return self.blob[int(self.off[i]) - base:int(self.off[i + 1]) - base].decode()
+
+    def __iter__(self):
+        text, base = self.blob, int(self.off[0])
+        o = (self.off - base).tolist()
+        for k in range(len(o) - 1):
+            yield text[o[k]:o[k + 1]].decode()
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def packed(self):
+        """-> (blob, offsets starting at 0)"""
+        return self.blob, (self.off - self.off[0] if self.off[0] else self.off)
+
+
+def junction_names(chrom_names, chrom, left, right, strand):
+    """NameTable of 'chrom:left-right:strand' (SPLICEDICE.py:312-314) for row-ordered junction arrays: chrom = index into
+    chrom_names, strand = index into STRAND_SYM (sdice_junction_names)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    cblob, coff = _names_blob(chrom_names)
+    ch, lf, rt = (np.ascontiguousarray(a, dtype=np.int32) for a in (chrom, left, right))
+    sym = np.frombuffer("".join(STRAND_SYM).encode(), dtype=np.uint8)
+    st = np.ascontiguousarray(sym[np.asarray(strand, dtype=np.int64)]) if ch.size else np.zeros(0, dtype=np.uint8)
+    n = ch.size
+    assert lf.size == rt.size == st.size == n
+    longest = max((len(str(c).encode()) for c in chrom_names), default=0)
+    cap = n * (longest + 26)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.int64)
+    need = C.c_int64()
+    _ffi.check(lib.sdice_junction_names(n, C.c_char_p(cblob), coff.ctypes.data_as(C.c_void_p), len(chrom_names),
+                                        ch.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p), rt.ctypes.data_as(C.c_void_p),
+                                        st.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), cap,
+                                        off.ctypes.data_as(C.c_void_p), C.byref(need)), "sdice_junction_names")
+    return NameTable(out[:need.value].tobytes(), off)
+
+
+def _names_blob(names):
+    """names (NameTable or any sequence) -> (one byte string, int64 offsets [n + 1])"""
+    if isinstance(names, NameTable):
+        return names.packed()
+    blobs = [str(nm).encode() for nm in names]
+    off = np.zeros(len(blobs) + 1, dtype=np.int64)
+    if blobs:
+        np.cumsum([len(b) for b in blobs], out=off[1:])
+    return b"".join(blobs), off
+
+
 def write_table(path, header, names, data, mode, threads=0, append=False):
     """Write `header` + one 'name<TAB>values' line per row through the library's multithreaded
     formatter (sdice_write_table).  mode: '.3f' | '.0f' | 'repr' (numpy str of float32/float64).
@@ -71,11 +150,7 @@ def write_table(path, header, names, data, mode, threads=0, append=False):
     n = len(names)
     s = data.shape[1] if data.ndim == 2 else 0
     assert data.shape[0] == n
-    blobs = [str(nm).encode() for nm in names]
-    off = np.zeros(n + 1, dtype=np.int64)
-    if n:
-        np.cumsum([len(b) for b in blobs], out=off[1:])
-    blob = b"".join(blobs)
+    blob, off = _names_blob(names)
     rc = lib.sdice_write_table(str(path).encode(), header.encode(), n, s, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
                                data.ctypes.data_as(C.c_void_p), _DTYPE_CODE[data.dtype],
                                _MODE_CODE[mode] | (0x100 if append else 0), int(threads))
@@ -95,11 +170,7 @@ def write_columns(path, header, names, columns, modes, threads=0, suffixes=None)
     for c in cols:
         if c.dtype not in _DTYPE_CODE or c.shape != (n,):
             raise TypeError(f"write_columns: unsupported column {c.dtype} {c.shape}")
-    blobs = [str(nm).encode() for nm in names]
-    off = np.zeros(n + 1, dtype=np.int64)
-    if n:
-        np.cumsum([len(b) for b in blobs], out=off[1:])
-    blob = b"".join(blobs)
+    blob, off = _names_blob(names)
     ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
     dts = np.array([_DTYPE_CODE[c.dtype] for c in cols], dtype=np.int32)
     mds = np.array([_MODE_CODE[m] for m in modes], dtype=np.int32)
@@ -150,11 +221,7 @@ def write_clusters(path, names, row_ptr, col, threads=0):
     from . import _ffi
     lib = _ffi.load()
     n = len(names)
-    blobs = [str(nm).encode() for nm in names]
-    off = np.zeros(n + 1, dtype=np.int64)
-    if n:
-        np.cumsum([len(b) for b in blobs], out=off[1:])
-    blob = b"".join(blobs)
+    blob, off = _names_blob(names)
     rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
     cl = np.ascontiguousarray(col, dtype=np.int32)
     assert rp.size == n + 1
@@ -169,11 +236,7 @@ def write_junction_bed(path, chrom_names, chrom, left, right, strand, threads=0)
     import ctypes as C
     from . import _ffi
     lib = _ffi.load()
-    blobs = [str(c).encode() for c in chrom_names]
-    off = np.zeros(len(blobs) + 1, dtype=np.int64)
-    if blobs:
-        np.cumsum([len(b) for b in blobs], out=off[1:])
-    blob = b"".join(blobs)
+    blob, off = _names_blob(chrom_names)
     ch = np.ascontiguousarray(chrom, dtype=np.int32)
     lf = np.ascontiguousarray(left, dtype=np.int32)
     rt = np.ascontiguousarray(right, dtype=np.int32)
@@ -181,7 +244,7 @@ def write_junction_bed(path, chrom_names, chrom, left, right, strand, threads=0)
     st = np.ascontiguousarray(sym[np.asarray(strand, dtype=np.int64)]) if ch.size else np.zeros(0, dtype=np.uint8)
     assert ch.size == lf.size == rt.size == st.size
     rc = lib.sdice_write_junction_bed(str(path).encode(), ch.size, C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
-                                      len(blobs), ch.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                                      len(chrom_names), ch.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
                                       rt.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), int(threads))
     _ffi.check(rc, "sdice_write_junction_bed")
 

@@ -258,3 +258,36 @@ def test_count_column_and_transpose_against_numpy():
         assert lib.sdice_transpose_i32(shape[0], shape[1], vp(src), vp(dst), 0) == 0
         assert np.array_equal(dst, src.T)
     assert lib.sdice_host_threads() >= 1
+
+
+def test_name_table_is_the_list_of_names(tmp_path):
+    """textio.junction_names (sdice_junction_names) against the f-string of SPLICEDICE.py:312-314; the writers give the
+    same bytes for a NameTable, a slice of one, and the list."""
+    rng = np.random.default_rng(3)
+    chroms = ["chr1", "chr10", "chrUn_KI270742v1", "X"]
+    n = 3000
+    c = rng.integers(0, len(chroms), n).astype(np.int32)
+    l = rng.integers(0, 2 ** 31 - 1, n).astype(np.int32)
+    r = rng.integers(0, 2 ** 31 - 1, n).astype(np.int32)
+    l[:3], r[:3] = [0, 7, 2 ** 31 - 1], [0, 12345678, 1]
+    st = rng.integers(0, 2, n).astype(np.int8)
+    want = [f"{chroms[a]}:{b}-{d}:{'+-'[e]}" for a, b, d, e in zip(c, l, r, st)]
+    names = textio.junction_names(chroms, c, l, r, st)
+    assert len(names) == n and list(names) == want and names[5] == want[5] and names[-1] == want[-1]
+    assert list(names[10:20]) == want[10:20] and names[10:20][3] == want[13] and len(names[7:7]) == 0
+    assert list(textio.junction_names(chroms, c[:0], l[:0], r[:0], st[:0])) == []
+    with pytest.raises(IndexError):
+        names[n]
+    data = rng.random((n, 3)).astype(np.float32)
+    a, b, d = (str(tmp_path / f"{k}.tsv") for k in "abd")
+    textio.write_table(a, "cluster\tx\ty\tz\n", want, data, ".3f")
+    textio.write_table(b, "cluster\tx\ty\tz\n", names, data, ".3f")
+    assert open(a, "rb").read() == open(b, "rb").read()
+    textio.write_table(a, "", want[100:900], data[100:900], ".3f")
+    textio.write_table(d, "", names[100:900], data[100:900], ".3f")
+    assert open(a, "rb").read() == open(d, "rb").read()
+    rp = np.arange(n + 1, dtype=np.int64)
+    col = rng.integers(0, n, n).astype(np.int32)
+    textio.write_clusters(a, want, rp, col)
+    textio.write_clusters(b, names, rp, col)
+    assert open(a, "rb").read() == open(b, "rb").read()
