@@ -246,6 +246,8 @@ int sdice_write_clusters(const char* path, int64_t n, const char* names, const i
 int sdice_write_junction_bed(const char* path, int64_t n, const char* chrom_names, const int64_t* chrom_off,
                              int32_t n_chrom, const int32_t* chrom, const int32_t* left, const int32_t* right,
                              const char* strand, int threads);
+/* sdice_write_table keeps its threads' text buffers between calls (a table written in slabs); this frees them. */
+int sdice_textio_trim(void);
 /* Row names 'chrom:left-right:strand' (SPLICEDICE.py:312-314) of n junction rows as one byte string + off[n + 1], the
  * form the table writers above take their names in.  *need = bytes the names take; out_cap too small (or out NULL, to
  * ask for the size): SDICE_ERR_ARG with off and *need filled. */

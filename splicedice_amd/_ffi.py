@@ -68,6 +68,7 @@ SIGNATURES = {
     "sdice_write_columns_sfx": [C.c_char_p, C.c_char_p, C.c_int64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_int],
     "sdice_interval_overlaps": [C.c_int64, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_int64, C.c_int],
     "sdice_write_junction_bed": [C.c_char_p, C.c_int64, vp, vp, C.c_int32, vp, vp, vp, vp, C.c_int],
+    "sdice_textio_trim": [],
     "sdice_junction_names": [C.c_int64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_int64, vp, c_i64p],
     "sdice_write_columns": [C.c_char_p, C.c_char_p, C.c_int64, vp, vp, C.c_int32, vp, vp, vp, C.c_int],
     "sdice_table_open": [C.c_char_p, C.POINTER(vp), c_i64p, C.POINTER(C.c_int32), c_i64p, c_i64p],

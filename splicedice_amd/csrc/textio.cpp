@@ -10,6 +10,7 @@
 // and with its readers (numpy string -> float64 -> dtype; compareSampleSets.py:202,
 // pairwise_fisher.py:60, counts_to_ps.py:50).  No device code here.
 #include <atomic>
+#include <cerrno>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -230,6 +231,39 @@ void parallel_rows(int64_t n, int threads, F&& fn) {
 // mode: 0 = '%.3f', 1 = '%.0f', 2 = numpy str() shortest repr; + 0x100: append to an existing file (a table
 //       streamed in row slabs -- `pairwise` at config-4 size writes 32 GB of p-values this way)
 // dtype: 0 = float32, 1 = float64, 2 = int32 (mode 1 only)
+namespace {
+struct FdCloser {
+    int fd;
+    ~FdCloser() { if (fd >= 0) close(fd); }
+};
+// all of [p, p + len) at file offset `at` (pwrite may stop short; EINTR is retried)
+inline bool write_all_at(int fd, const char* p, size_t len, off_t at) {
+    while (len > 0) {
+        const ssize_t w = pwrite(fd, p, len, at);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        if (w == 0) return false;
+        p += w; len -= (size_t)w; at += w;
+    }
+    return true;
+}
+// text buffers of the table writer's threads, kept between calls (sdice_textio_trim frees them)
+struct WBufPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<char[]>> buf;
+    std::vector<size_t> cap;
+};
+WBufPool g_wpool;
+}  // namespace
+
+// frees the writer's text buffers (they are kept between calls: see sdice_write_table)
+extern "C" int sdice_textio_trim(void) {
+    std::lock_guard<std::mutex> g(g_wpool.mu);
+    g_wpool.buf.clear();
+    g_wpool.cap.clear();
+    g_wpool.buf.shrink_to_fit();
+    return SDICE_OK;
+}
+
 extern "C" int sdice_write_table(const char* path, const char* header, int64_t n, int32_t s, const char* names,
                                  const int64_t* name_off, const void* data, int dtype, int mode, int threads) try {
     if (!path || !header || n < 0 || s < 0 || (n > 0 && (!names || !name_off || (!data && s > 0)))) {
@@ -242,15 +276,30 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
         sdice_set_error("sdice_write_table: unsupported dtype/mode combination");
         return SDICE_ERR_ARG;
     }
-    FILE* fh = fopen(path, append ? "ab" : "wb");
-    if (!fh) {
+    // The text leaves through a file DESCRIPTOR: every formatting thread writes its own piece at its own offset
+    // (pwrite: the copy into the page cache, ~10 GB per `pairwise` table, was one thread's work behind fwrite).
+    FdCloser fd{open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666)};
+    if (fd.fd < 0) {
         sdice_set_error("sdice_write_table: cannot open %s", path);
         return SDICE_ERR_ARG;
     }
-    fwrite(header, 1, strlen(header), fh);
+    off_t file_pos = append ? lseek(fd.fd, 0, SEEK_END) : 0;
+    if (file_pos < 0 || !write_all_at(fd.fd, header, strlen(header), file_pos)) {
+        sdice_set_error("sdice_write_table: short write to %s", path);
+        return SDICE_ERR_ARG;
+    }
+    file_pos += (off_t)strlen(header);
     // rows are formatted in blocks so that memory stays bounded and the writes stay ordered
     const int64_t block = 1 << 16;
     int nthreads = threads > 0 ? threads : default_threads();
+    // the threads' text buffers outlive the call (a `pairwise` table comes in ~60 slabs of ~1 GB of text each: fresh
+    // buffers per slab are a quarter of a million page faults per slab); a second writer at the same time brings its own
+    std::unique_lock<std::mutex> pool_lock(g_wpool.mu, std::try_to_lock);
+    const bool pooled = pool_lock.owns_lock();
+    std::vector<std::unique_ptr<char[]>> own_bufs;
+    std::vector<size_t> own_caps;
+    std::vector<std::unique_ptr<char[]>>& bufs = pooled ? g_wpool.buf : own_bufs;
+    std::vector<size_t>& caps = pooled ? g_wpool.cap : own_caps;
     for (int64_t r0 = 0; r0 < n; r0 += block) {
         const int64_t nb = std::min(block, n - r0);
         // threads by CELLS, not rows: a `pairwise` slab is ~1 700 rows of 19 900 columns (deciding by rows left that
@@ -258,14 +307,16 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
         int used = nb * (int64_t)std::max(s, 1) < 65536 ? 1 : std::min(nthreads, 64);
         if (used < 1) used = 1;
         if ((int64_t)used > nb) used = (int)nb;
-        std::vector<std::unique_ptr<char[]>> raws((size_t)used);
+        if (bufs.size() < (size_t)used) { bufs.resize((size_t)used); caps.resize((size_t)used, 0); }
         std::vector<size_t> lens((size_t)used, 0);
         const auto t_fmt = std::chrono::steady_clock::now();
         parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
             // worst case per cell: tab + 26 characters (numpy repr of a double, '%.3f' / '%.0f' of a count or PS value
             // below 1e21; anything longer takes the slow path through a temporary) -- written with a bare pointer
             size_t cap = (size_t)(name_off[r0 + b] - name_off[r0 + a]) + (size_t)(b - a) * ((size_t)s * 27 + 1) + 64;
-            std::unique_ptr<char[]> raw(new char[cap]);
+            std::unique_ptr<char[]>& raw = bufs[(size_t)t];          // (slot t is this thread's for the block)
+            if (caps[(size_t)t] < cap) { raw.reset(); raw.reset(new char[cap]); caps[(size_t)t] = cap; }
+            cap = caps[(size_t)t];
             char* o = raw.get();
             std::string tmp;
             for (int64_t r = r0 + a; r < r0 + b; ++r) {
@@ -289,6 +340,7 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
                             std::unique_ptr<char[]> bigger(new char[cap + tmp.size()]);
                             memcpy(bigger.get(), raw.get(), used_b);
                             raw.swap(bigger);
+                            caps[(size_t)t] = cap + tmp.size();
                             o = raw.get() + used_b;
                         }
                         memcpy(o, tmp.data(), tmp.size()); o += tmp.size();
@@ -297,23 +349,29 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
                 *o++ = '\n';
             }
             lens[(size_t)t] = (size_t)(o - raw.get());
-            raws[(size_t)t] = std::move(raw);
         });
         const auto t_wr = std::chrono::steady_clock::now();
-        for (int t = 0; t < used; ++t) {
-            if (lens[(size_t)t] && fwrite(raws[(size_t)t].get(), 1, lens[(size_t)t], fh) != lens[(size_t)t]) {
-                fclose(fh);
-                sdice_set_error("sdice_write_table: short write to %s", path);
-                return SDICE_ERR_ARG;
-            }
-            g_io_stats[2] += (double)lens[(size_t)t];
+        std::vector<off_t> at((size_t)used + 1, file_pos);
+        for (int t = 0; t < used; ++t) at[(size_t)t + 1] = at[(size_t)t] + (off_t)lens[(size_t)t];
+        std::atomic<bool> short_write{false};
+        parallel_rows(used, used, [&](int, int64_t a, int64_t b) {
+            for (int64_t t = a; t < b; ++t)
+                if (lens[(size_t)t] && !write_all_at(fd.fd, bufs[(size_t)t].get(), lens[(size_t)t], at[(size_t)t])) short_write = true;
+        });
+        if (short_write) {
+            sdice_set_error("sdice_write_table: short write to %s", path);
+            return SDICE_ERR_ARG;
         }
+        file_pos = at[(size_t)used];
+        g_io_stats[2] += (double)(at[(size_t)used] - at[0]);
         const auto t_end = std::chrono::steady_clock::now();
         g_io_stats[0] += std::chrono::duration<double>(t_wr - t_fmt).count();
         g_io_stats[1] += std::chrono::duration<double>(t_end - t_wr).count();
     }
     const auto t_cl = std::chrono::steady_clock::now();
-    if (fclose(fh) != 0) {
+    const int fdv = fd.fd;
+    fd.fd = -1;
+    if (close(fdv) != 0) {
         sdice_set_error("sdice_write_table: close failed for %s", path);
         return SDICE_ERR_ARG;
     }

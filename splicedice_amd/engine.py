@@ -37,8 +37,12 @@ class DeviceArray:
         check(self.ctx.lib.sdice_h2d(self.ctx.h, self.ptr, _ptr(host), self.nbytes), "sdice_h2d")
         return self
 
-    def to_host(self):
-        out = np.empty(self.shape, dtype=self.dtype)
+    def to_host(self, out=None):
+        """-> host copy (into `out`, a C-contiguous array of the same dtype and size, when given)"""
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        else:
+            assert out.dtype == self.dtype and out.flags.c_contiguous and out.nbytes == self.nbytes
         check(self.ctx.lib.sdice_d2h(self.ctx.h, _ptr(out), self.ptr, self.nbytes), "sdice_d2h")
         return out
 

@@ -128,13 +128,29 @@ def device_pipeline(ctx, counts, row_ptr, col, chi2, correction, events, header,
         ctx.bh_columns_dev(d_p)
     ctx.sync()
     t_kernels.__exit__(None, None, None)
-    slab = max(1, SLAB_BYTES // (pairs * 8))
-    for r0 in range(0, n, slab):
+    # two host slabs: the next one comes down (a thread of its own; the library call releases the GIL) while the
+    # current one is formatted and written
+    from concurrent.futures import ThreadPoolExecutor
+    slab = max(1, SLAB_BYTES // (2 * pairs * 8))
+    starts = list(range(0, n, slab))
+    bufs = [np.empty((min(slab, n), pairs), np.float64) for _ in range(min(2, len(starts)))]
+
+    def fetch(i):
+        r0 = starts[i]
         k = min(slab, n - r0)
-        with _stages.stage("d2h"):
-            host = d_p.offset(r0 * pairs, (k, pairs)).to_host()
-        with _stages.stage("format+write"):
-            textio.write_table(path, header if r0 == 0 else "", events[r0:r0 + k], host, "repr", append=r0 > 0)
+        return d_p.offset(r0 * pairs, (k, pairs)).to_host(out=bufs[i % 2][:k])
+
+    try:
+        with ThreadPoolExecutor(1) as pool:
+            nxt = pool.submit(fetch, 0) if starts else None
+            for i, r0 in enumerate(starts):
+                with _stages.stage("d2h"):
+                    host = nxt.result()
+                nxt = pool.submit(fetch, i + 1) if i + 1 < len(starts) else None
+                with _stages.stage("format+write"):
+                    textio.write_table(path, header if r0 == 0 else "", events[r0:r0 + host.shape[0]], host, "repr", append=r0 > 0)
+    finally:
+        textio.trim()
     d_p.free()
 
 

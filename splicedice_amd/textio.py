@@ -126,6 +126,12 @@ def junction_names(chrom_names, chrom, left, right, strand):
     return NameTable(out[:need.value].tobytes(), off)
 
 
+def trim():
+    """free the text buffers the table writer keeps between calls (sdice_textio_trim)"""
+    from . import _ffi
+    _ffi.load().sdice_textio_trim()
+
+
 def _names_blob(names):
     """names (NameTable or any sequence) -> (one byte string, int64 offsets [n + 1])"""
     if isinstance(names, NameTable):
