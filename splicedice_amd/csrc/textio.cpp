@@ -308,65 +308,92 @@ extern "C" int sdice_write_table(const char* path, const char* header, int64_t n
         if (used < 1) used = 1;
         if ((int64_t)used > nb) used = (int)nb;
         if (bufs.size() < (size_t)used) { bufs.resize((size_t)used); caps.resize((size_t)used, 0); }
-        std::vector<size_t> lens((size_t)used, 0);
-        const auto t_fmt = std::chrono::steady_clock::now();
-        parallel_rows(nb, used, [&](int t, int64_t a, int64_t b) {
-            // worst case per cell: tab + 26 characters (numpy repr of a double, '%.3f' / '%.0f' of a count or PS value
-            // below 1e21; anything longer takes the slow path through a temporary) -- written with a bare pointer
-            size_t cap = (size_t)(name_off[r0 + b] - name_off[r0 + a]) + (size_t)(b - a) * ((size_t)s * 27 + 1) + 64;
-            std::unique_ptr<char[]>& raw = bufs[(size_t)t];          // (slot t is this thread's for the block)
-            if (caps[(size_t)t] < cap) { raw.reset(); raw.reset(new char[cap]); caps[(size_t)t] = cap; }
-            cap = caps[(size_t)t];
-            char* o = raw.get();
-            std::string tmp;
-            for (int64_t r = r0 + a; r < r0 + b; ++r) {
-                const size_t nl = (size_t)(name_off[r + 1] - name_off[r]);
-                memcpy(o, names + name_off[r], nl); o += nl;
-                for (int32_t c = 0; c < s; ++c) {
-                    *o++ = '\t';
-                    const size_t i = (size_t)r * (size_t)s + (size_t)c;
-                    if (dtype == 2) {
-                        auto rr = std::to_chars(o, o + 16, ((const int32_t*)data)[i]);
-                        o = rr.ptr;
-                    } else if (mode == 2) {
-                        o = dtype == 0 ? repr_to<float>(o, ((const float*)data)[i]) : repr_to<double>(o, ((const double*)data)[i]);
-                    } else {
-                        const double v = dtype == 0 ? (double)((const float*)data)[i] : ((const double*)data)[i];
-                        tmp.clear();
-                        if (mode == 0) put_fixed3(tmp, v); else put_fixed0(tmp, v);
-                        if (tmp.size() > 26) {                      // (a count beyond 1e21: grow the buffer)
-                            const size_t used_b = (size_t)(o - raw.get());
-                            cap += tmp.size() + 64;
-                            std::unique_ptr<char[]> bigger(new char[cap + tmp.size()]);
-                            memcpy(bigger.get(), raw.get(), used_b);
-                            raw.swap(bigger);
-                            caps[(size_t)t] = cap + tmp.size();
-                            o = raw.get() + used_b;
+        // The block goes out in CHUNKS dealt round-robin to the threads: a thread formats chunk c, waits until the chunk
+        // before it has published where it ends (off[c]), publishes its own end, and writes its text there itself.
+        // Buffered writes to one file take turns inside the kernel (the inode lock: 16 threads writing at once moved
+        // the same 9.4 GB/s as one), so the gain is not parallel writing but that the other threads keep FORMATTING
+        // while one is in write(): per `pairwise` table 1.5 s of formatting and 1.05 s of writing, back to back before.
+        const int64_t n_chunks = std::min<int64_t>(nb, (int64_t)used * 8);
+        std::vector<std::atomic<int64_t>> off((size_t)n_chunks + 1);
+        for (auto& o : off) o.store(-1, std::memory_order_relaxed);
+        off[0].store((int64_t)file_pos, std::memory_order_release);
+        std::atomic<bool> failed{false};
+        std::vector<double> fmt_s((size_t)used, 0.0), wr_s((size_t)used, 0.0);
+        parallel_rows(used, used, [&](int, int64_t t_lo, int64_t t_hi) {
+          for (int64_t t = t_lo; t < t_hi; ++t) {
+            try {
+                std::string tmp;
+                for (int64_t ch = t; ch < n_chunks && !failed.load(std::memory_order_relaxed); ch += used) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const int64_t a = nb * ch / n_chunks, b = nb * (ch + 1) / n_chunks;
+                    // worst case per cell: tab + 26 characters (numpy repr of a double, '%.3f' / '%.0f' of a count or PS
+                    // value below 1e21; anything longer takes the slow path through a temporary) -- written with a bare pointer
+                    size_t cap = (size_t)(name_off[r0 + b] - name_off[r0 + a]) + (size_t)(b - a) * ((size_t)s * 27 + 1) + 64;
+                    std::unique_ptr<char[]>& raw = bufs[(size_t)t];          // (slot t is this thread's for the block)
+                    if (caps[(size_t)t] < cap) { raw.reset(); raw.reset(new char[cap]); caps[(size_t)t] = cap; }
+                    cap = caps[(size_t)t];
+                    char* o = raw.get();
+                    for (int64_t r = r0 + a; r < r0 + b; ++r) {
+                        const size_t nl = (size_t)(name_off[r + 1] - name_off[r]);
+                        memcpy(o, names + name_off[r], nl); o += nl;
+                        for (int32_t c = 0; c < s; ++c) {
+                            *o++ = '\t';
+                            const size_t i = (size_t)r * (size_t)s + (size_t)c;
+                            if (dtype == 2) {
+                                auto rr = std::to_chars(o, o + 16, ((const int32_t*)data)[i]);
+                                o = rr.ptr;
+                            } else if (mode == 2) {
+                                o = dtype == 0 ? repr_to<float>(o, ((const float*)data)[i]) : repr_to<double>(o, ((const double*)data)[i]);
+                            } else {
+                                const double v = dtype == 0 ? (double)((const float*)data)[i] : ((const double*)data)[i];
+                                tmp.clear();
+                                if (mode == 0) put_fixed3(tmp, v); else put_fixed0(tmp, v);
+                                if (tmp.size() > 26) {                      // (a count beyond 1e21: grow the buffer)
+                                    const size_t used_b = (size_t)(o - raw.get());
+                                    cap += tmp.size() + 64;
+                                    std::unique_ptr<char[]> bigger(new char[cap + tmp.size()]);
+                                    memcpy(bigger.get(), raw.get(), used_b);
+                                    raw.swap(bigger);
+                                    caps[(size_t)t] = cap + tmp.size();
+                                    o = raw.get() + used_b;
+                                }
+                                memcpy(o, tmp.data(), tmp.size()); o += tmp.size();
+                            }
                         }
-                        memcpy(o, tmp.data(), tmp.size()); o += tmp.size();
+                        *o++ = '\n';
                     }
+                    const int64_t len = (int64_t)(o - raw.get());
+                    const auto t1 = std::chrono::steady_clock::now();
+                    int64_t at;
+                    while ((at = off[(size_t)ch].load(std::memory_order_acquire)) < 0) {
+                        if (failed.load(std::memory_order_relaxed)) break;
+                        std::this_thread::yield();
+                    }
+                    if (at < 0) break;
+                    off[(size_t)ch + 1].store(at + len, std::memory_order_release);     // (before the write: the next chunk may go)
+                    if (len && !write_all_at(fd.fd, raw.get(), (size_t)len, (off_t)at)) failed.store(true);
+                    const auto t2 = std::chrono::steady_clock::now();
+                    fmt_s[(size_t)t] += std::chrono::duration<double>(t1 - t0).count();
+                    wr_s[(size_t)t] += std::chrono::duration<double>(t2 - t1).count();
                 }
-                *o++ = '\n';
+            } catch (...) {
+                failed.store(true);            // (the threads that wait for this one's offsets give up)
+                throw;
             }
-            lens[(size_t)t] = (size_t)(o - raw.get());
+          }
         });
-        const auto t_wr = std::chrono::steady_clock::now();
-        std::vector<off_t> at((size_t)used + 1, file_pos);
-        for (int t = 0; t < used; ++t) at[(size_t)t + 1] = at[(size_t)t] + (off_t)lens[(size_t)t];
-        std::atomic<bool> short_write{false};
-        parallel_rows(used, used, [&](int, int64_t a, int64_t b) {
-            for (int64_t t = a; t < b; ++t)
-                if (lens[(size_t)t] && !write_all_at(fd.fd, bufs[(size_t)t].get(), lens[(size_t)t], at[(size_t)t])) short_write = true;
-        });
-        if (short_write) {
+        const int64_t end_pos = off[(size_t)n_chunks].load(std::memory_order_acquire);
+        if (failed.load() || end_pos < 0) {
             sdice_set_error("sdice_write_table: short write to %s", path);
             return SDICE_ERR_ARG;
         }
-        file_pos = at[(size_t)used];
-        g_io_stats[2] += (double)(at[(size_t)used] - at[0]);
-        const auto t_end = std::chrono::steady_clock::now();
-        g_io_stats[0] += std::chrono::duration<double>(t_wr - t_fmt).count();
-        g_io_stats[1] += std::chrono::duration<double>(t_end - t_wr).count();
+        g_io_stats[2] += (double)(end_pos - (int64_t)file_pos);
+        file_pos = (off_t)end_pos;
+        // (formatting and writing overlap now: the split reported is the threads' mean time in either)
+        double fs = 0.0, ws = 0.0;
+        for (int t = 0; t < used; ++t) { fs += fmt_s[(size_t)t]; ws += wr_s[(size_t)t]; }
+        g_io_stats[0] += fs / used;
+        g_io_stats[1] += ws / used;
     }
     const auto t_cl = std::chrono::steady_clock::now();
     const int fdv = fd.fd;
