@@ -27,12 +27,13 @@ def column_indices(group, cols):
     return np.nonzero(np.isin(cols, group))[0].astype(np.int32)
 
 
-def read_ps_table(path):
-    """`_allPS.tsv` -> (row names array, column names array, float32 matrix), :193-204."""
+def read_ps_table(path, as_table=False):
+    """`_allPS.tsv` -> (row names array, column names array, float32 matrix), :193-204.  as_table: the row names as a
+    textio.NameTable (one byte string + offsets: a million-row table costs no Python string per row)."""
     from . import textio
-    header, rows, matrix = textio.read_table_numeric(path, np.float32)     # text -> float64 -> float32, as numpy
+    header, rows, matrix = textio.read_table_numeric(path, np.float32, as_table=as_table)     # text -> float64 -> float32, as numpy
     headers = header.strip().split("\t")[1:]
-    return np.array(rows), np.array(headers), matrix
+    return (rows if as_table else np.array(rows)), np.array(headers), matrix
 
 
 def read_annotation(gtf_path):
@@ -196,7 +197,7 @@ def run_with(args, ctx=None):
 
     from . import _stages
     with _stages.stage("parse"):
-        rows, cols, matrix = read_ps_table(args.psiSPLICEDICE)
+        rows, cols, matrix = read_ps_table(args.psiSPLICEDICE, as_table=True)
     g1_idx = column_indices(g1, cols)
     g2_idx = column_indices(g2, cols)
 
@@ -216,12 +217,12 @@ def run_with(args, ctx=None):
         # numeric table only: the library's multithreaded formatter (numpy str() of float32 /
         # float64 per column, byte-identical to the reference's print(*fields, sep="\t"))
         with _stages.stage("format+write"):
-            textio.write_columns(args.outputFile, base_header + "\n", [rows[ri] for ri in keep],
+            textio.write_columns(args.outputFile, base_header + "\n", rows.take(keep),
                                  [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
                                  ["repr"] * 7)
         return
     from . import textio
-    names = [rows[ri] for ri in keep]
+    names = list(rows.take(keep))
     textio.write_columns(args.outputFile, base_header + "\tgene\toverlapping\ttranscript_id\n", names,
                          [r["mean1"], r["mean2"], r["med1"], r["med2"], r["delta"], r["p"], r["corrected"]],
                          ["repr"] * 7, suffixes=annotation_suffixes(names, args.annotation))

@@ -97,6 +97,19 @@ class NameTable:
     def __eq__(self, other):
         return list(self) == list(other)
 
+    def take(self, idx):
+        """rows idx (an index array) as a new NameTable; the whole table in order is returned as it is"""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = len(self)
+        if idx.size == n and (n == 0 or (idx[0] == 0 and idx[-1] == n - 1 and np.all(np.diff(idx) == 1))):
+            return self
+        rel = self.off - self.off[0]
+        lens = rel[idx + 1] - rel[idx]
+        off = np.zeros(idx.size + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        src = np.repeat(rel[idx] - off[:-1], lens) + np.arange(off[-1], dtype=np.int64)
+        return NameTable(np.frombuffer(self.blob, dtype=np.uint8)[src].tobytes(), off)
+
     def packed(self):
         """-> (blob, offsets starting at 0)"""
         return self.blob, (self.off - self.off[0] if self.off[0] else self.off)
@@ -255,9 +268,9 @@ def write_junction_bed(path, chrom_names, chrom, left, right, strand, threads=0)
     _ffi.check(rc, "sdice_write_junction_bed")
 
 
-def read_table_numeric(path, dtype=np.float32, threads=0):
+def read_table_numeric(path, dtype=np.float32, threads=0, as_table=False):
     """-> (header_line, names list, data[n, s]) through the library's mmap + multithreaded parser
-    (numpy semantics: text -> float64 -> dtype)."""
+    (numpy semantics: text -> float64 -> dtype).  as_table: the names as a NameTable (no Python string per row)."""
     import ctypes as C
     from . import _ffi
     lib = _ffi.load()
@@ -276,6 +289,8 @@ def read_table_numeric(path, dtype=np.float32, threads=0):
                                         code, int(threads)), "sdice_table_read")
     finally:
         lib.sdice_table_close(h)
+    if as_table:
+        return header.raw[:hb.value].decode(), NameTable(names.raw[:nb.value], off), data
     text = names.raw[:nb.value].decode()
     name_list = [text[off[i]:off[i + 1]] for i in range(n.value)] if text.isascii() else \
         [names.raw[off[i]:off[i + 1]].decode() for i in range(n.value)]

@@ -291,3 +291,21 @@ def test_name_table_is_the_list_of_names(tmp_path):
     textio.write_clusters(a, want, rp, col)
     textio.write_clusters(b, names, rp, col)
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_name_table_take_and_table_reader(tmp_path):
+    rng = np.random.default_rng(8)
+    names = [f"chr{rng.integers(1, 23)}:{rng.integers(1, 10 ** 8)}-{rng.integers(1, 10 ** 8)}:+" for _ in range(2000)] + ["", "x"]
+    data = rng.random((len(names), 4)).astype(np.float32)
+    path = str(tmp_path / "t.tsv")
+    textio.write_table(path, "cluster\ta\tb\tc\td\n", names[:-2], data[:-2], ".3f")
+    header, table, mat = textio.read_table_numeric(path, np.float32, as_table=True)
+    header2, listed, mat2 = textio.read_table_numeric(path, np.float32)
+    assert isinstance(table, textio.NameTable) and list(table) == listed == names[:-2] and header == header2
+    assert np.array_equal(mat, mat2)
+    blob = "".join(names).encode()
+    t = textio.NameTable(blob, np.cumsum([0] + [len(x) for x in names]))
+    idx = rng.permutation(len(names))[:700]
+    assert list(t.take(idx)) == [names[i] for i in idx]
+    assert t.take(np.arange(len(names))) is t and len(t.take(np.zeros(0, np.int64))) == 0
+    assert list(t[5:900].take([3, 0, 3])) == [names[8], names[5], names[8]]
