@@ -657,15 +657,16 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 }
 
 // Exclusive prefix of `agg` over the tiles before `tile` (called by the 64 lanes of one wave).
-// Forward progress: the neighbour kernel is launched with AT MOST as many workgroups as the device holds at once
-// (launch_neighbours: occupancy x CUs), and a workgroup takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... in
-// increasing order, publishing a tile's aggregate before it waits for anything.  Every workgroup of the grid is resident
-// at some point and stays until it is through its tiles, so the owner of the smallest unfinished tile is either running
-// or about to be dispatched into a slot that only workgroups of OTHER kernels can be holding -- it never waits on an
-// unfinished tile, and every wait ends whatever order the dispatcher chooses.  (Rounds 1-3 launched one workgroup per tile
-// and relied on in-order dispatch; a device-side ticket would also do, measured at 22 us per 1 954 tiles.)  The spin stays
-// bounded all the same: a wait that outlasts ~1 s gives up, flags ST_LOOKBACK (the chain's result is then discarded: the
-// synchronous caller falls back to the generic path, the asynchronous one reports it at the next sync) and the grid drains.
+// Forward progress: EVERY tile is drawn from a device-side ticket counter by a workgroup that is already running, in
+// increasing order, and a workgroup publishes a tile's aggregate before it waits for anything.  The tiles before a given
+// one therefore all belong to workgroups that hold a CU and never wait on a later tile: every wait ends, whatever the
+// dispatcher does and whoever else is on the device.  (Rounds 1-3 launched one workgroup per tile and relied on in-order
+// dispatch.  The first version of this loop gave a workgroup its FIRST tile by block index: with two processes on one GPU
+// -- two neighbour kernels of capped grids, each holding CUs the other's not-yet-dispatched workgroups needed -- both
+// chains waited on tiles nobody had started and gave up; `tools/gpu_rehearse2.sh`.)  The grid is capped at what the device
+// holds at once (launch_neighbours) only to save dispatches.  The spin stays bounded all the same: a wait that outlasts
+// ~1 s gives up, flags ST_LOOKBACK (the chain's result is then discarded: the synchronous caller falls back to the generic
+// path, the asynchronous one reports it at the next sync) and the grid drains.
 // fail: cluster.ablate & 256 (tests; the one ablation bit that is compiled into the shipped kernel): tile 1 gives up at once.
 __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* state, int tile, unsigned long long agg,
                                                                  int lane, unsigned long long* sb, bool fail) {
@@ -765,13 +766,15 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
     const int n = (int)a.n;
     const int n_tiles = (n + T - 1) / T;
     const bool failed_chain = (a.sb[SB_FLAGS] & (ST_INVALID | ST_SLOT_OVERFLOW | ST_DUP)) != 0;
-    // a workgroup takes its tiles in increasing order (see lookback_exclusive): its first tile is its id, every further
-    // one comes from a counter (tickets gridDim.x, gridDim.x + 1, ...: a workgroup that drew cheap tiles takes more of
-    // them, as the dispatcher would have arranged; a fixed stride cost 30 % of the kernel at 2 M junctions)
+    // a workgroup draws its tiles from a counter (see lookback_exclusive; a workgroup that drew cheap tiles takes more of
+    // them, as the dispatcher would have arranged: a fixed stride cost 30 % of the kernel at 2 M junctions).  A failed
+    // chain (no look-back) walks by stride.
     __shared__ int s_tile;
     unsigned long long* ticket = a.tile_state + n_tiles;
+    if (t == 0) s_tile = failed_chain ? (int)blockIdx.x : (int)atomicAdd(ticket, 1ull);
+    __syncthreads();
 #pragma nounroll
-    for (int tile = blockIdx.x; tile < n_tiles;) {
+    for (int tile = s_tile; tile < n_tiles;) {
     const int t0 = tile * T;
     const int nr = min(T, n - t0);
     if (failed_chain) {
@@ -993,7 +996,7 @@ __global__ void __launch_bounds__(T, 8) neighbours_kernel(FastArgs a) {      // 
         walk_fwd_global(a, r + 1, n, c, rgt, st, put);
     }
     // next tile (the barrier also says: this tile's readers are done with the LDS)
-    if (t == 0) s_tile = (int)gridDim.x + (int)atomicAdd(ticket, 1ull);
+    if (t == 0) s_tile = (int)atomicAdd(ticket, 1ull);
     __syncthreads();
     tile = s_tile;
     }   // tile loop
