@@ -783,10 +783,12 @@ __global__ void __launch_bounds__(T) bhs_bucket_kernel(BhsArgs a) {
     if (!done && threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1u)] = seg_x * a.B + k % a.B;
 }
 
-// the listed buckets in turn: up to 2048 values by the workgroup (8 per thread, with the second-level pass for crowded
-// bins), beyond that (or beyond bh.reg_cap) by its first wave in HBM.  (Workgroups of 512 / 1024 threads for the large buckets were measured: the barriers between
-// the phases cost more than the larger bucket saves -- DESIGN.md appendix A.4.)
-__global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
+// the listed buckets in turn: up to 2048 values by the workgroup (T x K slots, with the second-level pass for crowded
+// bins), beyond that (or beyond bh.reg_cap) by its first wave in HBM.  (512 / 1024 threads for ALL buckets were measured:
+// the barriers between the phases cost more than the larger bucket saves -- EXPERIMENTS.md A.4; for the listed ones alone
+// see the launch.)
+template <int T, int K>
+__global__ void __launch_bounds__(T) bhs_bucket_big_kernel(BhsArgs a) {
     extern __shared__ uint64_t smem_bk[];
     const unsigned n_big = *a.big_count;
 #pragma nounroll
@@ -796,7 +798,7 @@ __global__ void __launch_bounds__(256) bhs_bucket_big_kernel(BhsArgs a) {
         if ((r.n_b > a.reg_cap && !r.pd) || r.n_b > 2048) {
             if (threadIdx.x < 64) bucket_in_hbm(a, r.ks, r.n_b, r.start, (int)threadIdx.x, r.bm);
         } else {
-            bucket_wg_rank<256, 8, true>(a, r, smem_bk);
+            bucket_wg_rank<T, K, true>(a, r, smem_bk);
         }
         __syncthreads();
     }
@@ -1487,7 +1489,13 @@ int sd_bh_cols_samplesort(sdice_ctx* ctx, int64_t m, int64_t segs, double* d_rm,
         SD_LAUNCH(ctx, "bhs_bucket_kernel", (bhs_bucket_kernel<1024>), dim3((unsigned)bucket_blocks), dim3(1024), (bucket_wg_lds<1024, 4>()), a);
     }
     const int64_t big_blocks = std::max<int64_t>(1, std::min<int64_t>(n_buckets, (int64_t)ctx->n_cu * 4));
-    SD_LAUNCH(ctx, "bhs_bucket_big_kernel", bhs_bucket_big_kernel, dim3((unsigned)big_blocks), dim3(256), (bucket_wg_lds<256, 8>()), a);
+    // the listed buckets of 1 025 ... 2 048 values: 512 threads x 4 values (109 VGPRs) take 0.61 ms on the bench's table where
+    // 256 x 8 (173 VGPRs, two waves per SIMD) take 0.77
+    if (ctx->param("bh.big_wg", 512) >= 512) {
+        SD_LAUNCH(ctx, "bhs_bucket_big_kernel", (bhs_bucket_big_kernel<512, 4>), dim3((unsigned)big_blocks), dim3(512), (bucket_wg_lds<512, 4>()), a);
+    } else {
+        SD_LAUNCH(ctx, "bhs_bucket_big_kernel", (bhs_bucket_big_kernel<256, 8>), dim3((unsigned)big_blocks), dim3(256), (bucket_wg_lds<256, 8>()), a);
+    }
     SD_LAUNCH(ctx, "bhs_bucket_zoom_kernel", bhs_bucket_zoom_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_buckets, (int64_t)ctx->n_cu * 6))), dim3(256), (bucket_wg_lds<256, 4>()), a);
     SD_LAUNCH(ctx, "bhs_suffix_kernel", bhs_suffix_kernel, dim3((unsigned)segs), dim3(256), 0, a);
     // bh.finish_cols: columns per workgroup of the last kernel (16: full 128-byte lines out, 3.2 MB of results per strip

@@ -338,7 +338,7 @@ extern "C" int sdice_set_param(sdice_ctx* ctx, const char* name, int64_t value) 
     SD_ARG(ctx && name, "bad arguments");
     static const char* known[] = {"ps.lds_bytes", "ps.tile_rows", "ps.threads", "ps.chunk_cols",
                                   "ps.xcd_remap", "ps.halo_rows", "cluster.generic", "cluster.legacy", "cluster.lds_cap", "cluster.ablate", "cluster.nb_grid", "cluster.sample_sort", "cluster.bucket_mean", "cluster.spb", "cluster.max_nnz", "ps.ablate", "ps.quantize3", "ps.prio", "ps.nt_loads", "ps.gen1", "ps.use_reach", "sort.rounds", "ranksum.variant", "ranksum.ablate",
-                                  "fisher.table_max", "fisher.refill", "fisher.unroll", "fisher.count_steps", "bh.columns_path", "bh.vector_path", "bhv.mean", "bhv.cap", "bh.reg_cap", "bh.mean", "bh.rows_per_block", "bh.fused_count", "bh.finish_cols", "bh.finish_nt", "bh.wg", "bh.spb", nullptr};
+                                  "fisher.table_max", "fisher.refill", "fisher.unroll", "fisher.count_steps", "bh.columns_path", "bh.vector_path", "bhv.mean", "bhv.cap", "bh.reg_cap", "bh.mean", "bh.rows_per_block", "bh.fused_count", "bh.finish_cols", "bh.finish_nt", "bh.wg", "bh.big_wg", "bh.spb", nullptr};
     for (int i = 0; known[i]; ++i)
         if (strcmp(known[i], name) == 0) {
             ctx->params[name] = value;

@@ -294,17 +294,18 @@ def gen_bh(ctx, rng):
     elif kind == 5:
         p[:] = np.sort(p, axis=0)[::-1] if rng.random() < 0.5 else np.sort(p, axis=0)
     wg, mean, fused = int(rng.choice([256, 256, 512, 1024])), int(rng.choice([0, 0, 100, 700, 2500])), int(rng.integers(0, 2))
+    big_wg = int(rng.choice([256, 512]))
     try:
         ctx.set_param("bh.columns_path", 1)
         d = ctx.to_device(p); ctx.bh_columns_dev(d); generic = d.to_host()
         ctx.set_param("bh.columns_path", 2)
-        ctx.set_param("bh.wg", wg); ctx.set_param("bh.mean", mean); ctx.set_param("bh.fused_count", fused)
+        ctx.set_param("bh.wg", wg); ctx.set_param("bh.mean", mean); ctx.set_param("bh.fused_count", fused); ctx.set_param("bh.big_wg", big_wg)
         d = ctx.to_device(p); ctx.bh_columns_dev(d); fast = d.to_host()
     finally:
         ctx.set_param("bh.columns_path", 0)
-        ctx.set_param("bh.wg", 256); ctx.set_param("bh.mean", 0); ctx.set_param("bh.fused_count", 1)
+        ctx.set_param("bh.wg", 256); ctx.set_param("bh.mean", 0); ctx.set_param("bh.fused_count", 1); ctx.set_param("bh.big_wg", 512)
     if not np.array_equal(generic, fast, equal_nan=True):
-        return f"bh columns: sample-sort path != generic path (n={n} cols={cols} kind={kind} wg={wg} mean={mean} fused={fused})"
+        return f"bh columns: sample-sort path != generic path (n={n} cols={cols} kind={kind} wg={wg} mean={mean} fused={fused} big_wg={big_wg})"
     if kind == 8:
         return None                                   # (the oracle's definition is for proper p-values)
     if n <= 5000 and not np.allclose(fast, O.bh_columns(p), rtol=1e-14, atol=0):

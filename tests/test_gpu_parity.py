@@ -831,6 +831,12 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
             ctx.bh_columns_dev(d)
             assert np.array_equal(generic, d.to_host(), equal_nan=True), (wg, mean)
         ctx.set_param("bh.wg", 256)
+        ctx.set_param("bh.mean", 900)
+        ctx.set_param("bh.big_wg", 256)                                       # the listed buckets at 256 threads x 8 values
+        d = ctx.to_device(p)
+        ctx.bh_columns_dev(d)
+        assert np.array_equal(generic, d.to_host(), equal_nan=True)
+        ctx.set_param("bh.big_wg", 512)
         ctx.set_param("bh.mean", 0)
         ctx.set_param("bh.fused_count", 0)                                    # transpose and count as two kernels
         d = ctx.to_device(p)
@@ -847,6 +853,7 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
         ctx.set_param("bh.reg_cap", 2048)
         ctx.set_param("bh.mean", 0)
         ctx.set_param("bh.wg", 256)
+        ctx.set_param("bh.big_wg", 512)
         ctx.set_param("bh.fused_count", 1)
     ok = ~np.isnan(p).any(axis=0)
     np.testing.assert_allclose(fast[:, ok], O.bh_columns(p[:, ok]), rtol=1e-14, atol=0)
