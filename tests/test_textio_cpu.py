@@ -309,3 +309,36 @@ def test_name_table_take_and_table_reader(tmp_path):
     assert list(t.take(idx)) == [names[i] for i in idx]
     assert t.take(np.arange(len(names))) is t and len(t.take(np.zeros(0, np.int64))) == 0
     assert list(t[5:900].take([3, 0, 3])) == [names[8], names[5], names[8]]
+
+
+def test_pack_keys_against_numpy():
+    """sdice_junc_pack_keys: chromosome ranks and the order-preserving 12 | 31 | 20 | 1-bit keys of the admitted lines, and
+    the flag for junctions that do not fit the packing (juncio._unpack_keys is the inverse)."""
+    from splicedice_amd import juncio
+    rng = np.random.default_rng(21)
+    n = 4000
+    rec = dict(chroms=["chrB", "chrA", "chrC"], chrom_id=rng.integers(0, 3, n).astype(np.int32),
+               left=rng.integers(0, 2 ** 31 - 2 ** 20, n).astype(np.int32), strand=rng.integers(0, 2, n).astype(np.int8),
+               admit=(rng.random(n) < 0.7).astype(np.uint8))
+    rec["right"] = (rec["left"] + rng.integers(0, 2 ** 20, n)).astype(np.int32)
+    rank = {"chrA": 0, "chrB": 1, "chrC": 2}
+    juncio._rank_and_pack(rec, rank)
+    want_rank = np.array([1, 0, 2], np.int32)[rec["chrom_id"]]
+    assert np.array_equal(rec["chrom_rank"], want_rank) and rec["packable"]
+    a = rec["admit"].astype(bool)
+    want = ((want_rank[a].astype(np.uint64) << np.uint64(52)) | (rec["left"][a].astype(np.uint64) << np.uint64(21))
+            | ((rec["right"][a].astype(np.int64) - rec["left"][a]).astype(np.uint64) << np.uint64(1)) | rec["strand"][a].astype(np.uint64))
+    assert np.array_equal(rec["keys"], want)
+    c, l, r, s = juncio._unpack_keys(np.sort(rec["keys"]))
+    order = np.lexsort((rec["strand"][a], rec["right"][a], rec["left"][a], want_rank[a]))
+    assert np.array_equal(c, want_rank[a][order]) and np.array_equal(l, rec["left"][a][order])
+    assert np.array_equal(r, rec["right"][a][order]) and np.array_equal(s, rec["strand"][a][order])
+    for bad in ("span", "negative"):
+        rec2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in rec.items() if k not in ("keys", "packable", "chrom_rank")}
+        i = int(np.flatnonzero(a)[5])
+        if bad == "span":
+            rec2["left"][i], rec2["right"][i] = 10, 10 + 2 ** 20
+        else:
+            rec2["left"][i], rec2["right"][i] = -5, 40
+        juncio._rank_and_pack(rec2, rank)
+        assert not rec2["packable"] and rec2["keys"].size == int(a.sum()) - 1
