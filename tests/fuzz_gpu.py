@@ -269,9 +269,14 @@ def gen_bh(ctx, rng):
     if n * cols > 1_500_000:
         cols = max(1, 1_500_000 // n)
     p = rng.random((n, cols)) ** float(rng.choice([1, 3, 20]))
-    kind = int(rng.integers(0, 10))
+    kind = int(rng.integers(0, 11))
     if kind == 1:
         p[rng.random((n, cols)) < 0.6] = 1.0
+    elif kind == 10:                                  # the top of a Fisher column: exact ones, a crowd of distinct sums a few
+        q = rng.random((n, cols))                     # hundred ulps below 1 (heavy-tailed), ordinary values
+        p[q < 0.06] = 1.0
+        m = (q >= 0.06) & (q < 0.2)
+        p[m] = 1.0 - (np.abs(rng.standard_cauchy(int(m.sum()))) * 30 + 1).astype(np.int64).clip(1, 10 ** 6) * 2.0 ** -53
     elif kind == 6:                                   # a dense cluster of DISTINCT values inside a wide range: one bin of the
         m = rng.random((n, cols)) < 0.5               # bucket's counting sort holds many different keys
         p[m] = 0.3 + rng.integers(0, 4000, size=int(m.sum())) * 2.0 ** -52

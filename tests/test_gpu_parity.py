@@ -802,7 +802,7 @@ def test_bh_columns_batched(ctx, n, cols):
 def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
     """the sample-sort column path (bh_cols.hip) against the generic radix path, bit for bit, and the oracle:
     continuous values, heavy ties (p = 1, a few discrete levels as Fisher gives), one-value and two-value
-    columns, values a few ulps apart, NaN"""
+    columns, values a few ulps apart, NaN, crowds of distinct values far narrower than a bin (the second-level sort)"""
     rng = np.random.default_rng(n * 31 + cols)
     p = rng.random((n, cols)) ** 2
     p[rng.random((n, cols)) < 0.3] = 1.0
@@ -814,6 +814,17 @@ def test_bh_columns_samplesort_vs_generic(ctx, n, cols):
         p[:, 3] = 0.5 + rng.integers(0, 7, size=n) * 2.0 ** -53              # a few ulps apart
     if cols > 4 and n > 10:
         p[rng.integers(0, n, size=3), 4] = np.nan
+    if cols > 5:
+        # what a column of Fisher p-values looks like at its top: exact ones, a crowd of DISTINCT sums within 1e-13 of 1
+        # (many keys in ONE bin of the bucket's counting sort, next to a tie group), ordinary values below
+        q = rng.random(n)
+        p[q < 0.06, 5] = 1.0
+        crowd = (q >= 0.06) & (q < 0.14)
+        p[crowd, 5] = 1.0 - rng.integers(1, 900, size=int(crowd.sum())) * 2.0 ** -53
+    if cols > 6:
+        # a crowd with a long tail around an ordinary value, and a stray neighbour inside the same bin
+        crowd = rng.random(n) < 0.3
+        p[crowd, 6] = 0.3 + (rng.standard_cauchy(int(crowd.sum())) * 40).astype(np.int64).clip(-10 ** 7, 10 ** 7) * 2.0 ** -54
     try:
         ctx.set_param("bh.columns_path", 1)
         d = ctx.to_device(p)
