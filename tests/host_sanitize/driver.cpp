@@ -9,7 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "sdice.h"
 
@@ -98,6 +100,38 @@ int main(int argc, char** argv) {
         for (int64_t i = 0; i < n; ++i) CHECK(out[i] == (int32_t)i);
         int32_t qc = 3, ql = 7, qr = 8; int8_t qs = 1; int32_t o1 = 0;
         CHECK(sdice_junc_lookup(n, rc.data(), rl.data(), rr.data(), rs8.data(), 1, &qc, &ql, &qr, &qs, &o1, 1) == 0 && o1 == -1);
+    }
+    {   // count columns side by side + transpose, key packing, row names (the ingest's second half)
+        const int64_t nr = 20000; const int32_t ns = 6;
+        std::vector<int32_t> rc(nr), rl(nr), rr(nr); std::vector<int8_t> rs8(nr);
+        for (int64_t i = 0; i < nr; ++i) { rc[i] = (int32_t)(i / 5000); rl[i] = (int32_t)(i % 5000) * 10; rr[i] = rl[i] + 7; rs8[i] = (int8_t)(i & 1); }
+        std::vector<int32_t> table_t((size_t)ns * nr, 0), table((size_t)ns * nr, -1);
+        std::vector<uint8_t> low((size_t)ns * nr, 0);
+        std::vector<int64_t> score(nr);
+        for (int64_t i = 0; i < nr; ++i) score[i] = i % 9;
+        std::vector<std::thread> pool;
+        std::atomic<int> bad{0};
+        for (int32_t c = 0; c < ns; ++c)
+            pool.emplace_back([&, c] {
+                if (sdice_junc_count_column(nr, rc.data(), rl.data(), rr.data(), rs8.data(), nr, rc.data(), rl.data(), rr.data(), rs8.data(),
+                                            score.data(), 5, table_t.data() + (size_t)c * nr, low.data() + (size_t)c * nr) != 0) bad++;
+            });
+        for (auto& th : pool) th.join();
+        CHECK(bad == 0);
+        CHECK(sdice_transpose_i32(ns, nr, table_t.data(), table.data(), 4) == 0);
+        for (int64_t i = 0; i < nr; i += 997) for (int32_t c = 0; c < ns; ++c) CHECK(table[(size_t)i * ns + c] == (int32_t)(i % 9) && low[(size_t)c * nr + i] == (i % 9 < 5));
+        int32_t rank_of[4] = {2, 0, 3, 1};
+        std::vector<int32_t> crank(nr); std::vector<uint64_t> keys(nr); std::vector<uint8_t> admit(nr, 1);
+        int64_t nk = 0; int32_t packable = 0;
+        CHECK(sdice_junc_pack_keys(nr, rc.data(), rank_of, 4, rl.data(), rr.data(), rs8.data(), admit.data(), crank.data(), keys.data(), &nk, &packable) == 0);
+        CHECK(nk == nr && packable == 1 && crank[5000] == 0 && (keys[1] >> 52) == 2);
+        const char cnames[] = "chrAchrBBchrCchrDDD"; int64_t coff[5] = {0, 4, 9, 13, 19};
+        std::vector<char> strand(nr); for (int64_t i = 0; i < nr; ++i) strand[i] = rs8[i] ? '-' : '+';
+        std::vector<char> nm((size_t)nr * 40); std::vector<int64_t> noff(nr + 1); int64_t need = 0;
+        CHECK(sdice_junction_names(nr, cnames, coff, 4, rc.data(), rl.data(), rr.data(), strand.data(), nm.data(), (int64_t)nm.size(), noff.data(), &need) == 0);
+        CHECK(need == noff[nr] && std::string(nm.data() + noff[1], (size_t)(noff[2] - noff[1])) == "chrA:10-17:-");
+        CHECK(sdice_junction_names(nr, cnames, coff, 4, rc.data(), rl.data(), rr.data(), strand.data(), nm.data(), 10, noff.data(), &need) != 0);
+        CHECK(sdice_host_threads() >= 1 && sdice_textio_trim() == 0);
     }
     printf("host sanitizer driver: ok\n");
     return 0;
