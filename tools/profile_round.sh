@@ -2,6 +2,7 @@
 # rocprofv3 summaries for one round (run on the GPU box through gpurun from the repo root):
 #   tools/profile_round.sh r04            (every workload)
 #   tools/profile_round.sh r04 compare    (one workload's trace + traffic passes only; summarise locally afterwards)
+#   tools/profile_round.sh r04 full       (kernel traces of BASELINE configs 4 and 5 at FULL size on the one GPU)
 # kernel-trace/stats and the PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass;
 # counters are never combined with the trace domains).  The program itself follows `--` (python3 bench.py).
 # Workloads: quant = the headline (2M x 500), quantc2 = BASELINE config 2 (1M x 100), compare, pairwise, e2e.
@@ -31,6 +32,13 @@ short_args_of() {   # fewer steps for the counter passes (one counter per run)
 }
 WLS="quant quantc2 compare pairwise e2e"
 [ -n "$ONLY" ] && WLS=$ONLY
+if [ "$ONLY" = "full" ]; then   # BASELINE configs 4 and 5 at full size: kernel trace + stats only
+  echo "trace pairwisefull"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pairwisefull_trace -- python3 bench.py --workload pairwise --junctions 200000 --steps 2 --warmup 1 $COMMON > $OUT/pairwisefull_bench.json 2> $OUT/pairwisefull_trace.err
+  echo "trace e2efull"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2efull_trace -- python3 bench.py --workload e2e --junctions 5000000 --samples 1000 --steps 3 --warmup 1 $COMMON > $OUT/e2efull_bench.json 2> $OUT/e2efull_trace.err
+  exit 0
+fi
 for WL in $WLS; do
   echo "trace $WL"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${WL}_trace -- python3 bench.py $(args_of $WL) $COMMON > $OUT/${WL}_bench.json 2> $OUT/${WL}_trace.err

@@ -29,7 +29,8 @@ def src_sha16(files):
 
 KERNEL_SOURCES = {"quant": ["ps.hip"], "compare": ["ranksum.hip"], "pairwise": ["fisher.hip"], "e2e": ["ranksum.hip"]}
 
-for wl in ("quant", "quantc2", "compare", "pairwise", "e2e"):
+# (pairwisefull / e2efull: BASELINE configs 4 and 5 at full size on the one GPU, kernel trace only -- profile_round.sh RR full)
+for wl in ("quant", "quantc2", "compare", "pairwise", "e2e", "pairwisefull", "e2efull"):
     files = newest(os.path.join(src, f"{wl}_trace", "*", "*_kernel_stats.csv"))
     if not files:
         continue
