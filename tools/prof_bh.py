@@ -33,12 +33,13 @@ if sys.argv[2] == "fisher":
 else:
     cols = int(sys.argv[2])
     rng = np.random.default_rng(1)
-    blk = rng.random((min(n, 2000), cols)) ** 2
-    blk[rng.random(blk.shape) < 0.2] = 1.0
     d_src = ctx.empty((n, cols), np.float64)
-    for a in range(0, n, blk.shape[0]):
-        b = min(n, a + blk.shape[0])
-        d_src.offset(a * cols, (b - a, cols)).upload(np.roll(blk[: b - a], a, axis=1))
+    step = min(n, 2000)
+    for a in range(0, n, step):                     # (fresh values per block: a repeated block would fill long columns with ties)
+        b = min(n, a + step)
+        blk = rng.random((b - a, cols)) ** 2
+        blk[rng.random(blk.shape) < 0.2] = 1.0
+        d_src.offset(a * cols, (b - a, cols)).upload(blk)
 d = ctx.empty((n, cols), np.float64)
 for c in cfgs:
     kv = [x.split("=") for x in c.split(",") if x]
