@@ -37,6 +37,12 @@ if [ "$ONLY" = "full" ]; then   # BASELINE configs 4 and 5 at full size: kernel 
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pairwisefull_trace -- python3 bench.py --workload pairwise --junctions 200000 --steps 2 --warmup 1 $COMMON > $OUT/pairwisefull_bench.json 2> $OUT/pairwisefull_trace.err
   echo "trace e2efull"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2efull_trace -- python3 bench.py --workload e2e --junctions 5000000 --samples 1000 --steps 3 --warmup 1 $COMMON > $OUT/e2efull_bench.json 2> $OUT/e2efull_trace.err
+  for C in FETCH_SIZE WRITE_SIZE; do
+    echo "pmc pairwisefull $C"
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pairwisefull_pmc_$C -- python3 bench.py --workload pairwise --junctions 200000 --steps 1 --warmup 1 $COMMON > /dev/null 2> $OUT/pairwisefull_pmc_$C.err
+    echo "pmc e2efull $C"
+    rocprofv3 --pmc $C --output-format csv -d $OUT/e2efull_pmc_$C -- python3 bench.py --workload e2e --junctions 5000000 --samples 1000 --steps 1 --warmup 1 $COMMON > /dev/null 2> $OUT/e2efull_pmc_$C.err
+  done
   exit 0
 fi
 for WL in $WLS; do

@@ -51,7 +51,8 @@ for wl in ("quant", "quantc2", "compare", "pairwise", "e2e", "pairwisefull", "e2
 # (x2), WRITE_SIZE is exact.
 DOMINANT = [("quant", "quant", "ps_tile", 2000000, 500), ("quantc2", "quant", "ps_tile", 1000000, 100),
             ("compare", "compare", "ranksum_pair", 1000000, 100), ("pairwise", "pairwise", "fisher_pairs_kernel", 25000, 200),
-            ("e2e", "e2e", "ranksum_count_kernel", 625000, 1000)]
+            ("e2e", "e2e", "ranksum_count_kernel", 625000, 1000),
+            ("pairwisefull", "pairwise", "fisher_pairs_kernel", 200000, 200), ("e2efull", "e2e", "ranksum_count_kernel", 5000000, 1000)]
 records = []
 for wl, wl_key, dom, n, s in DOMINANT:
     traffic = {}
