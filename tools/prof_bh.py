@@ -59,6 +59,6 @@ for c in cfgs:
     rep = ctx.prof_report()
     ctx.prof_enable(0)
     for k, v in kv:
-        ctx.set_param(k, {"bh.reg_cap": 2048, "bh.mean": 0, "bh.wg": 256, "bh.spb": 8, "bh.fused_count": 1, "bh.rows_per_block": 2048, "bh.finish_cols": 16}.get(k, 0))
+        ctx.set_param(k, {"bh.reg_cap": 2048, "bh.mean": 0, "bh.wg": 256, "bh.big_wg": 512, "bh.spb": 8, "bh.fused_count": 1, "bh.rows_per_block": 2048, "bh.finish_cols": 16}.get(k, 0))
     tot = sum(ms for _, ms in rep.values()) / reps
     print(f"[{c}] total {tot:.3f} ms: " + ", ".join(f"{name} {ms / reps:.3f}" for name, (cnt, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])), flush=True)
